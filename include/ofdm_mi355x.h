@@ -1,0 +1,188 @@
+/*
+ * ofdm_mi355x.h -- C ABI of libofdm_mi355x.so (MI355X / gfx950 native OFDM baseband hot path).
+ *
+ * Drop-in boundary for the Task 1-5 TX -> channel -> RX path of ladnlav/OFDM-course.
+ * The reference has no FFI layer: its boundary is the MATLAB function-call interface
+ * (one `function` per .m file).  Each entry point below replaces
+ * exactly one reference function and is what a MEX gateway (mex/<name>.cpp, see
+ * INTEGRATION.md) binds.  "T5/x.m:a-b" = /root/reference/Task 5/x.m lines a-b.
+ *
+ * Conventions (all entries):
+ *   - arrays are MATLAB column-major; complex data is interleaved (re,im);
+ *   - `flags` bit0: OFDM_F64 -> data are double / complex double, else float / complex float;
+ *     the kernels compute in that same type (fp64 = parity mode, fp32 = throughput mode);
+ *   - `flags` bit1: OFDM_DEVICE -> every *data* pointer is a device (HBM) pointer and the call
+ *     is asynchronous on the library stream (ofdm_set_stream); otherwise data pointers are
+ *     host pointers, the library stages them through HBM and the call returns synchronised;
+ *   - index vectors (`*_carriers`, `pilot_loc`) are HOST int32 arrays holding the reference's
+ *     1-based carrier indices; scalar out-params are HOST pointers (a call that returns
+ *     scalars synchronises the stream);
+ *   - bit vectors are uint8 arrays of 0/1 (one byte per bit), except the fused chain which
+ *     uses packed bits (MSB-first inside each byte);
+ *   - inputs are never modified; outputs are caller-allocated;
+ *   - return value: 0 = ok, <0 = error (invalid argument / shape / HIP failure; text in
+ *     ofdm_last_error_string()), >0 = soft condition (documented per function).  Nothing
+ *     throws across the boundary.
+ */
+#ifndef OFDM_MI355X_H
+#define OFDM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDM_F32 0
+#define OFDM_F64 1
+#define OFDM_HOST 0
+#define OFDM_DEVICE 2
+
+/* status codes */
+#define OFDM_OK 0
+#define OFDM_ERR_ARG (-1)       /* invalid argument / shape (MATLAB would raise an error) */
+#define OFDM_ERR_HIP (-2)       /* HIP runtime failure */
+#define OFDM_ERR_STATE (-3)     /* library not initialised / no GPU */
+#define OFDM_ERR_UNSUPPORTED (-4)
+#define OFDM_SOFT_ACF_FALLBACK 1 /* AutoCorrFunction: plateau not found, TgPosition = 65 (T5/AutoCorrFunction.m:21-24) */
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int ofdm_init(int device_id);                 /* binds the calling process to one GPU          */
+int ofdm_shutdown(void);                      /* frees plan / twiddle caches (MEX: mexAtExit)  */
+const char* ofdm_last_error_string(void);
+int ofdm_set_stream(void* hip_stream);        /* hipStream_t to launch on (NULL = default)     */
+int ofdm_synchronize(void);
+int ofdm_version(void);
+
+/* ---- constellation / mapping (bit-exact) ------------------------------------------------- */
+/* T5/constellation_func.m:4-35.  name in {BPSK,QPSK,8PSK,16QAM} + extensions {64QAM,256QAM}.
+ * dict_out: 2^bps complex (host pointer always). */
+int ofdm_constellation_func(const char* name, void* dict_out, int* bps_out, int flags);
+
+/* T5/mapping.m:1-25.  bits[n_bits] -> iq[ceil(n_bits/bps)]; *pad_out = -1 when no padding. */
+int ofdm_mapping(const uint8_t* bits, int64_t n_bits, const char* constellation,
+                 void* iq_out, int* pad_out, int flags);
+
+/* T5/demapping.m:1-25.  iq[n_iq] -> bits_out[n_iq*bps - max(pad,0)] (hard decision, first min). */
+int ofdm_demapping(int pad, const void* iq, int64_t n_iq, const char* constellation,
+                   uint8_t* bits_out, int flags);
+
+/* ---- scrambler (bit-exact) --------------------------------------------------------------- */
+/* T5/Scrambler.m:1-28 / T5/DeScrambler.m:1-28.  reg[15] (host, uint8 0/1) is read AND updated
+ * with the final register (second output of the .m function). */
+int ofdm_Scrambler(uint8_t* reg15, const uint8_t* seq, int64_t n, uint8_t* out, int flags);
+int ofdm_DeScrambler(uint8_t* reg15, const uint8_t* seq, int64_t n, uint8_t* out, int flags);
+/* Per-frame batch used by the drivers (register reset to reg15 for every frame,
+ * T5/Main_model_Task_5.m:58-69): seq/out are [frame_len x n_frames] column-major. */
+int ofdm_Scrambler_frames(const uint8_t* reg15, const uint8_t* seq, int64_t frame_len,
+                          int64_t n_frames, uint8_t* out, int flags);
+int ofdm_DeScrambler_frames(const uint8_t* reg15, const uint8_t* seq, int64_t frame_len,
+                            int64_t n_frames, uint8_t* out, int flags);
+
+/* ---- carriers / OFDM (I)FFT + CP ---------------------------------------------------------- */
+/* T5/OFDM_map_carriers.m:2-9.  payload[n_data*n_symb]; pilot_values[n_pilots*n_symb] or a single
+ * complex value when pilot_scalar != 0 (T3/Main_model_Task_3.m:59); out[nfft*n_symb]. */
+int ofdm_OFDM_map_carriers(const void* payload, int64_t n_symb, int nfft,
+                           const int32_t* data_carriers, int n_data,
+                           const int32_t* pilot_carriers, int n_pilots,
+                           const void* pilot_values, int pilot_scalar, void* out, int flags);
+/* T5/get_payload.m:2-4.  x[nfft*n_symb] -> out[n_data*n_symb]. */
+int ofdm_get_payload(const void* x, int nfft, int64_t n_symb,
+                     const int32_t* data_carriers, int n_data, void* out, int flags);
+/* T5/OFDM_modulator.m:2-11.  x[nfft*n_symb] -> y[(nfft+t_guard)*n_symb] (ifft, 1/nfft, CP). */
+int ofdm_OFDM_modulator(const void* x, void* y, int nfft, int64_t n_symb, int t_guard, int flags);
+/* T5/OFDM_demodulator.m:2-10.  y[(nfft+t_guard)*n_symb] -> x[nfft*n_symb] (strip CP, fft). */
+int ofdm_OFDM_demodulator(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, int flags);
+
+/* ---- channel side ------------------------------------------------------------------------ */
+/* T5/get_MP_channel_resp.m:2-19.  taps: host double [n_taps x 2] column-major (delay, amplitude)
+ * (+ optional imaginary amplitudes taps_im[n_taps], may be NULL).  h_out[max_delay+1] and
+ * H_out[nfft] complex, HOST pointers; *h_len_out = max_delay+1. */
+int ofdm_get_MP_channel_resp(const double* taps, const double* taps_im, int n_taps, int nfft,
+                             void* h_out, int* h_len_out, void* H_out, int flags);
+/* conv(x,h.','full')(1:len) -- T5/Main_model_Task_5.m:126-127.  h is a HOST complex array. */
+int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void* y, int flags);
+/* T5/Noise.m:1-12 with a counter-based generator (Philox4x32-10 + Box-Muller, seed/stream):
+ * y = x + sqrt(P/snr/2)*(n_re + i n_im).  *n_var_out = sqrt(NoisePower) (Noise.m:11). */
+int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_t stream,
+               void* y, double* n_var_out, int flags);
+/* T5/add_STO.m:1-10 and T5/add_CFO.m:1-8. */
+int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags);
+int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, int flags);
+
+/* ---- synchronisation --------------------------------------------------------------------- */
+/* T5/AutoCorrFunction.m:1-28.  rho_out[len-width-nfft] complex (may be NULL);
+ * returns OFDM_SOFT_ACF_FALLBACK when the catch branch (:21-24) is taken. */
+int ofdm_AutoCorrFunction(const void* rx, int64_t len, int width_window, int nfft,
+                          void* rho_out, int64_t* tg_position_out, double* freq_offset_out, int flags);
+/* T5/remove_IFO.m:1-11. */
+int ofdm_remove_IFO(const void* rx, int64_t len, int nfft, void* fixed_out, int* ifo_out, int flags);
+/* T5/fine_sync.m:1-45 (variant 0) / T4/fine_sync.m:1-60 (variant 1).  pilot_values[n_pilots*n_symb].
+ * tau_out / phase_out (HOST, may be NULL) receive the two internal estimates. */
+int ofdm_fine_sync(const void* rx, int nfft, int64_t n_symb, const int32_t* pilot_carriers, int n_pilots,
+                   const void* pilot_values, int time_desync, int freq_desync, int variant,
+                   void* out, double* tau_out, double* phase_out, int flags);
+
+/* ---- channel estimation / equalisation ---------------------------------------------------- */
+/* T5/interpolate.m:1-24.  method: 'l'inear or 's'pline.  h[n_pilots] -> out[n_out]. */
+int ofdm_interpolate(const void* h, const int32_t* pilot_loc, int n_pilots, int n_out, char method,
+                     void* out, int flags);
+/* T5/estimate_channel.m:1-9.  all_carriers[n_all] (1-based query points). */
+int ofdm_estimate_channel(const void* rx, int nfft, int64_t n_symb, const int32_t* all_carriers, int n_all,
+                          const int32_t* pilot_carriers, int n_pilots, const void* pilot_values,
+                          void* h_est_out, void* h_pilots_out, int flags);
+/* T5/equalize_signal.m:1-8. */
+int ofdm_equalize_signal(const void* x, int nfft, int64_t n_symb, const void* h_est, int n_carrier,
+                         void* out, int flags);
+/* T5/LS_CE.m:1-34 (symbol 1 only).  y[nfft*n_symb], xp[n_pilots*n_symb] -> h_ls[n_carrier]. */
+int ofdm_LS_CE(const void* y, int nfft, int64_t n_symb, const void* xp, const int32_t* pilot_loc,
+               int n_pilots, int n_carrier, void* h_ls_out, int flags);
+/* T5/MMSE_CE.m:1-39.  h[h_len] = CIR guess, snr_db. */
+int ofdm_MMSE_CE(const void* y, int nfft, int64_t n_symb, const void* xp, const int32_t* pilot_loc,
+                 int n_pilots, int n_carrier, const void* h, int h_len, double snr_db,
+                 void* h_mmse_out, int flags);
+/* Sensing matrix of T5/Main_model_Task_5.m:182-190 in closed form: s_out[n_pilots x k]. */
+int ofdm_sensing_matrix(const int32_t* pilot_carriers, int n_pilots, int nfft, int k, void* s_out, int flags);
+/* T5/MP_estimate.m:1-34.  y[n_pilots], s[n_pilots x k]; H_out[nfft], h_out[nfft],
+ * picks_out[dominant_taps] (HOST int32, 1-based, may be NULL). */
+int ofdm_MP_estimate(const void* y, const void* s, int n_pilots, int k, int nfft, int dominant_taps,
+                     void* H_out, void* h_out, int32_t* picks_out, int flags);
+/* T5/OMP_estimate.m:1-37.  index_out[dominant_taps] (HOST, 1-based), *n_index_out = picks made. */
+int ofdm_OMP_estimate(const void* y, const void* s, int n_pilots, int k, int nfft, int dominant_taps,
+                      double snr_db, void* H_out, void* h_out, int32_t* index_out, int* n_index_out, int flags);
+
+/* ---- metrics ----------------------------------------------------------------------------- */
+/* T5/BER_func.m:1-7: *n_errors_out = sum(tx != rx) (HOST).  BER = n_errors / n. */
+int ofdm_BER_func(const uint8_t* bit_tx, const uint8_t* bit_rx, int64_t n, int64_t* n_errors_out, int flags);
+/* T5/MER_func.m:1-26. */
+int ofdm_MER_func(const void* iq, int64_t n, const char* constellation, double* mer_db_out, int flags);
+
+/* ---- fused Task-5 RX chain (the benchmark path; everything stays in HBM) -------------------- */
+/* Per frame of n_symb symbols (call order of T5/Task5_part2.m:169-193,:272,:279-303 with the
+ * sensing matrix of T5/Main_model_Task_5.m:182-190):
+ *   OFDM_demodulator -> Y = RX(pilots,1)./pilot -> OMP_estimate -> equalize_signal(1..n_carrier)
+ *   -> get_payload -> demapping -> BER_func against ref bits.
+ * The plan owns carrier index tables, the pilot column and the sensing matrix on the device. */
+typedef struct ofdm_rx_plan ofdm_rx_plan;
+int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_symb, int n_carrier,
+                        const int32_t* pilot_carriers, int n_pilots,
+                        const int32_t* data_carriers, int n_data,
+                        const void* pilot_values_col /* [n_pilots] complex, HOST */,
+                        int k_atoms, int dominant_taps, const char* constellation, int flags);
+int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
+/* rx[(nfft+t_guard)*n_symb*n_frames] (DEVICE or HOST per flags);
+ * bits_out: packed decided bits, per frame ceil(n_data*n_symb*bps/8)*... see ofdm_rx_plan_frame_bytes;
+ * ref_bits (may be NULL): packed reference bits, same layout;
+ * errors_out[n_frames] uint32 bit errors per frame (may be NULL when ref_bits is NULL);
+ * h_out (may be NULL): [n_carrier x n_frames] OMP estimate; index_out (may be NULL): [dominant_taps x n_frames]
+ * 1-based picks, 0 = unused slot. */
+int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
+int ofdm_rx_chain_task5(ofdm_rx_plan* plan, const void* rx, int64_t n_frames,
+                        uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out,
+                        void* h_out, int32_t* index_out, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDM_MI355X_H */

@@ -1,0 +1,625 @@
+"""Host-side mirror of the reference's operator interface (one Python function per `.m` file,
+same names, argument order and error behaviour) on top of the C ABI of libofdm_mi355x.so.
+
+Data arguments may be
+  * numpy arrays  -> host-pointer flavour of the ABI (what a MEX gateway does): the library stages
+    the data through HBM, runs the HIP kernels and copies the results back;
+  * torch CUDA tensors -> device-pointer flavour: zero-copy, asynchronous on torch's current stream.
+
+Precision follows the dtype of the primary argument: complex128/float64 -> fp64 kernels (parity
+mode, MATLAB is double everywhere), complex64/float32 -> fp32 kernels (throughput mode).
+Matrices use MATLAB shapes `[rows, cols]` and are handed to the library in column-major order.
+Index vectors are the reference's 1-based carrier indices.
+
+Nothing in this module computes on the CPU: every function ends in a C-ABI call, and a missing
+library / GPU raises OfdmError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import OfdmError  # noqa: F401
+
+try:  # torch is optional plumbing (device memory + streams)
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+__all__ = [
+    "OfdmError", "init", "shutdown", "constellation_func", "mapping", "demapping", "Scrambler",
+    "DeScrambler", "Scrambler_frames", "DeScrambler_frames", "OFDM_map_carriers", "get_payload",
+    "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
+    "add_CFO", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
+    "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
+    "MER_func", "RxPlan", "rx_chain_task5", "DEFAULT_REGISTER",
+]
+
+DEFAULT_REGISTER = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)   # T5/Main_model_Task_5.m:55
+
+
+def init(device_id: int = -1):
+    L.check(L.load().ofdm_init(int(device_id)), "ofdm_init")
+
+
+def shutdown():
+    L.check(L.load().ofdm_shutdown(), "ofdm_shutdown")
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class _Call:
+    """Marshals the arguments of one C-ABI call (placement + precision from the primary arg)."""
+
+    def __init__(self, primary, f64=None):
+        self.lib = L.load()
+        self.dev = _is_torch(primary) and primary.is_cuda
+        if _is_torch(primary) and not primary.is_cuda:
+            primary = primary.numpy()
+        if f64 is None:
+            if _is_torch(primary):
+                f64 = primary.dtype in (torch.complex128, torch.float64)
+            else:
+                dt = np.asarray(primary).dtype
+                f64 = dt not in (np.complex64, np.float32)
+        self.f64 = bool(f64)
+        self.flags = (L.OFDM_F64 if self.f64 else L.OFDM_F32) | (L.OFDM_DEVICE if self.dev else L.OFDM_HOST)
+        self.keep = []
+        if self.dev:
+            self.device = primary.device
+            init(self.device.index if self.device.index is not None else torch.cuda.current_device())
+            L.check(self.lib.ofdm_set_stream(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                    "ofdm_set_stream")
+        else:
+            L.check(self.lib.ofdm_set_stream(None), "ofdm_set_stream")
+
+    # ---- dtypes
+    @property
+    def cdt(self):
+        return np.complex128 if self.f64 else np.complex64
+
+    @property
+    def tcdt(self):
+        return torch.complex128 if self.f64 else torch.complex64
+
+    # ---- inputs
+    def _flat(self, x, npdt, tdt):
+        if self.dev:
+            if not _is_torch(x):
+                x = torch.as_tensor(np.asarray(x))
+            x = x.to(device=self.device, dtype=tdt)
+            if x.ndim >= 2:
+                x = x.movedim(tuple(range(x.ndim)), tuple(reversed(range(x.ndim)))).contiguous()
+            else:
+                x = x.contiguous()
+            self.keep.append(x)
+            return C.c_void_p(x.data_ptr()), x.numel()
+        if _is_torch(x):
+            x = x.cpu().numpy()
+        a = np.ascontiguousarray(np.asarray(x, dtype=npdt).ravel(order="F"))
+        self.keep.append(a)
+        return a.ctypes.data_as(C.c_void_p), a.size
+
+    def cin(self, x):
+        return self._flat(x, self.cdt, self.tcdt if self.dev else None)[0]
+
+    def bits_in(self, x):
+        if self.dev and _is_torch(x):
+            x = (x != 0)
+        elif not self.dev:
+            x = (np.asarray(x.cpu().numpy() if _is_torch(x) else x) != 0)
+        return self._flat(x, np.uint8, torch.uint8 if self.dev else None)[0]
+
+    def idx(self, v):
+        """1-based index vector (MATLAB doubles) -> host int32 array."""
+        if _is_torch(v):
+            v = v.cpu().numpy()
+        a = np.asarray(v).ravel()
+        r = np.rint(a).astype(np.int32)
+        if a.dtype.kind == "f" and not np.array_equal(r, a):
+            raise OfdmError("index vector must hold integers")
+        r = np.ascontiguousarray(r)
+        self.keep.append(r)
+        return r.ctypes.data_as(C.c_void_p), r.size
+
+    # ---- outputs
+    def cout(self, shape):
+        return self._out(shape, self.cdt, self.tcdt if self.dev else None)
+
+    def bits_out(self, n):
+        return self._out((int(n),), np.uint8, torch.uint8 if self.dev else None)
+
+    def _out(self, shape, npdt, tdt):
+        shape = tuple(int(s) for s in shape)
+        if self.dev:
+            t = torch.empty(tuple(reversed(shape)), dtype=tdt, device=self.device)
+            view = t.movedim(tuple(range(t.ndim)), tuple(reversed(range(t.ndim)))) if t.ndim >= 2 else t
+            self.keep.append(t)
+            return view, C.c_void_p(t.data_ptr())
+        a = np.empty(shape, dtype=npdt, order="F")
+        return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _shape2(x):
+    s = tuple(x.shape)
+    if len(s) == 1:
+        return (s[0], 1)
+    if len(s) != 2:
+        raise OfdmError("expected a vector or a matrix")
+    return s
+
+
+def _cstr(s):
+    return str(s).encode()
+
+
+# ------------------------------------------------------------------------------------------------
+# constellation / mapping / demapping
+# ------------------------------------------------------------------------------------------------
+
+def constellation_func(Constellation):
+    """T5/constellation_func.m:4-35 -> (Dictionary[2^bps] complex128, Bit_depth_Dict)."""
+    lib = L.load()
+    d = np.empty(256, dtype=np.complex128)
+    bps = C.c_int(0)
+    L.check(lib.ofdm_constellation_func(_cstr(Constellation), d.ctypes.data_as(C.c_void_p), C.byref(bps), L.OFDM_F64),
+            "constellation_func")
+    return d[: 1 << bps.value].copy(), bps.value
+
+
+def _bps(constellation):
+    bps = C.c_int(0)
+    L.check(L.load().ofdm_constellation_func(_cstr(constellation), None, C.byref(bps), 0), "constellation_func")
+    return bps.value
+
+
+def mapping(bits, constellation, precision="fp64"):
+    """T5/mapping.m:1-25 -> (IQ row, pad).  Row input that needs padding is an error (mapping.m:11)."""
+    bps = _bps(constellation)
+    shp = tuple(bits.shape)
+    n = int(np.prod(shp)) if len(shp) else 1
+    is_row = len(shp) == 2 and shp[0] == 1 and shp[1] > 1
+    if n % bps != 0 and is_row:
+        raise OfdmError("mapping: vertcat dimension mismatch (row input needs padding)")
+    call = _Call(bits if _is_torch(bits) else np.zeros(1, np.complex128 if precision == "fp64" else np.complex64),
+                 f64=(precision == "fp64"))
+    pb = call.bits_in(bits)
+    n_iq = (n + bps - 1) // bps
+    iq, piq = call.cout((n_iq,))
+    pad = C.c_int(0)
+    L.check(call.lib.ofdm_mapping(pb, n, _cstr(constellation), piq, C.byref(pad), call.flags), "mapping")
+    return iq, pad.value
+
+
+def demapping(pad, IQ, Constellation):
+    """T5/demapping.m:1-25 -> bit row (uint8 0/1)."""
+    bps = _bps(Constellation)
+    call = _Call(IQ)
+    n = int(np.prod(tuple(IQ.shape)))
+    nb = n * bps - (int(pad) if pad != -1 else 0)
+    if nb < 0:
+        raise OfdmError("demapping: pad larger than the bit count")
+    out, pout = call.bits_out(nb)
+    L.check(call.lib.ofdm_demapping(int(pad), call.cin(IQ), n, _cstr(Constellation), pout, call.flags), "demapping")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# scrambler
+# ------------------------------------------------------------------------------------------------
+
+def _scr(fn_name, Register, sequence):
+    call = _Call(sequence if _is_torch(sequence) else np.zeros(1, np.complex64), f64=False)
+    reg = np.ascontiguousarray((np.asarray(Register).ravel() != 0).astype(np.uint8))
+    if reg.size != 15:
+        raise OfdmError(f"{fn_name}: Register must have 15 elements")
+    n = int(np.prod(tuple(sequence.shape)))
+    out, pout = call.bits_out(n)
+    fn = getattr(call.lib, "ofdm_" + fn_name)
+    L.check(fn(reg.ctypes.data_as(C.c_void_p), call.bits_in(sequence), n, pout, call.flags), fn_name)
+    return out, reg
+
+
+def Scrambler(Register, sequence):
+    """T5/Scrambler.m:1-28 -> (sc_sequence, Register)."""
+    return _scr("Scrambler", Register, sequence)
+
+
+def DeScrambler(Register, sequence):
+    """T5/DeScrambler.m:1-28 -> (dsc_sequence, Register)."""
+    return _scr("DeScrambler", Register, sequence)
+
+
+def _scr_frames(fn_name, Register, seq_matrix):
+    call = _Call(seq_matrix if _is_torch(seq_matrix) else np.zeros(1, np.complex64), f64=False)
+    reg = np.ascontiguousarray((np.asarray(Register).ravel() != 0).astype(np.uint8))
+    flen, nfr = _shape2(seq_matrix)
+    out, pout = call._out((flen, nfr), np.uint8, torch.uint8 if call.dev else None)
+    fn = getattr(call.lib, "ofdm_" + fn_name)
+    L.check(fn(reg.ctypes.data_as(C.c_void_p), call.bits_in(seq_matrix), flen, nfr, pout, call.flags), fn_name)
+    return out
+
+
+def Scrambler_frames(Register, seq_matrix):
+    """Per-frame loop of T5/Main_model_Task_5.m:58-69: one column per frame, register reset per column."""
+    return _scr_frames("Scrambler_frames", Register, seq_matrix)
+
+
+def DeScrambler_frames(Register, seq_matrix):
+    """Per-frame loop of T5/Main_model_Task_5.m:260-271."""
+    return _scr_frames("DeScrambler_frames", Register, seq_matrix)
+
+
+# ------------------------------------------------------------------------------------------------
+# carriers, modulator, demodulator
+# ------------------------------------------------------------------------------------------------
+
+def OFDM_map_carriers(QAM_payload, N_symb, Nfft, dataCarriers, pilotCarriers, pilotValues):
+    """T5/OFDM_map_carriers.m:2-9."""
+    call = _Call(QAM_payload)
+    N_symb, Nfft = int(N_symb), int(Nfft)
+    pdc, nd = call.idx(dataCarriers)
+    ppc, npil = call.idx(pilotCarriers)
+    n_pay = int(np.prod(tuple(QAM_payload.shape)))
+    if n_pay != nd * N_symb:
+        raise OfdmError("OFDM_map_carriers: reshape size mismatch (payload != numel(dataCarriers)*N_symb)")
+    pv_n = int(np.prod(tuple(pilotValues.shape))) if hasattr(pilotValues, "shape") else 1
+    scalar = 1 if pv_n == 1 else 0
+    if not scalar and pv_n != npil * N_symb:
+        raise OfdmError("OFDM_map_carriers: pilotValues must be [numel(pilotCarriers) x N_symb] or scalar")
+    pv = pilotValues if hasattr(pilotValues, "shape") else np.asarray([pilotValues])
+    out, pout = call.cout((Nfft, N_symb))
+    L.check(call.lib.ofdm_OFDM_map_carriers(call.cin(QAM_payload), N_symb, Nfft, pdc, nd, ppc, npil,
+                                            call.cin(pv), scalar, pout, call.flags), "OFDM_map_carriers")
+    return out
+
+
+def get_payload(RX_OFDM_symbols, dataCarriers):
+    """T5/get_payload.m:2-4."""
+    call = _Call(RX_OFDM_symbols)
+    nfft, ns = _shape2(RX_OFDM_symbols)
+    pdc, nd = call.idx(dataCarriers)
+    out, pout = call.cout((nd, ns))
+    L.check(call.lib.ofdm_get_payload(call.cin(RX_OFDM_symbols), nfft, ns, pdc, nd, pout, call.flags), "get_payload")
+    return out
+
+
+def OFDM_modulator(OFDM_symbols, T_guard):
+    """T5/OFDM_modulator.m:2-11."""
+    call = _Call(OFDM_symbols)
+    nfft, ns = _shape2(OFDM_symbols)
+    tg = int(T_guard)
+    out, pout = call.cout((nfft + tg, ns))
+    L.check(call.lib.ofdm_OFDM_modulator(call.cin(OFDM_symbols), pout, nfft, ns, tg, call.flags), "OFDM_modulator")
+    return out
+
+
+def OFDM_demodulator(OFDM_time_guarded, T_guard):
+    """T5/OFDM_demodulator.m:2-10."""
+    call = _Call(OFDM_time_guarded)
+    rows, ns = _shape2(OFDM_time_guarded)
+    tg = int(T_guard)
+    nfft = rows - tg
+    out, pout = call.cout((nfft, ns))
+    L.check(call.lib.ofdm_OFDM_demodulator(call.cin(OFDM_time_guarded), pout, nfft, ns, tg, call.flags),
+            "OFDM_demodulator")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# channel side
+# ------------------------------------------------------------------------------------------------
+
+def get_MP_channel_resp(channel_taps, Nfft):
+    """T5/get_MP_channel_resp.m:2-19 -> (impulse_response row, frequency_response row), complex128."""
+    lib = L.load()
+    init()
+    taps = np.atleast_2d(np.asarray(channel_taps))
+    nt = taps.shape[0]
+    t_re = np.ascontiguousarray(np.real(taps).astype(np.float64).ravel(order="F"))
+    t_im = np.ascontiguousarray(np.imag(taps[:, 1]).astype(np.float64)) if np.iscomplexobj(taps) else None
+    maxd = int(np.max(np.real(taps[:, 0])))
+    h = np.empty(maxd + 1, dtype=np.complex128)
+    H = np.empty(int(Nfft), dtype=np.complex128)
+    hl = C.c_int(0)
+    L.check(lib.ofdm_get_MP_channel_resp(t_re.ctypes.data_as(C.c_void_p),
+                                         t_im.ctypes.data_as(C.c_void_p) if t_im is not None else None,
+                                         nt, int(Nfft), h.ctypes.data_as(C.c_void_p), C.byref(hl),
+                                         H.ctypes.data_as(C.c_void_p), L.OFDM_F64), "get_MP_channel_resp")
+    return h[: hl.value], H
+
+
+def apply_channel(x, h):
+    """conv(x, h.', 'full')(1:numel(x)) -- T5/Main_model_Task_5.m:126-127."""
+    call = _Call(x)
+    n = int(np.prod(tuple(x.shape)))
+    hh = np.ascontiguousarray(np.asarray(h.cpu().numpy() if _is_torch(h) else h).ravel().astype(call.cdt))
+    out, pout = call.cout((n,))
+    L.check(call.lib.ofdm_channel_conv(call.cin(x), n, hh.ctypes.data_as(C.c_void_p), hh.size, pout, call.flags),
+            "channel_conv")
+    return out
+
+
+def Noise(SNR, IQ_TX, seed=0, stream=0):
+    """T5/Noise.m:1-12 with the build's counter-based generator -> (IQ_RX, N_var)."""
+    call = _Call(IQ_TX)
+    n = int(np.prod(tuple(IQ_TX.shape)))
+    out, pout = call.cout(tuple(IQ_TX.shape) if len(IQ_TX.shape) <= 2 else (n,))
+    nv = C.c_double(0)
+    L.check(call.lib.ofdm_Noise(float(SNR), call.cin(IQ_TX), n, int(seed), int(stream), pout, C.byref(nv), call.flags),
+            "Noise")
+    return out, nv.value
+
+
+def add_STO(y, nSTO):
+    """T5/add_STO.m:1-10."""
+    call = _Call(y)
+    n = int(np.prod(tuple(y.shape)))
+    out, pout = call.cout((n,))
+    L.check(call.lib.ofdm_add_STO(call.cin(y), n, int(nSTO), pout, call.flags), "add_STO")
+    return out
+
+
+def add_CFO(y, CFO, Nfft):
+    """T5/add_CFO.m:1-8."""
+    call = _Call(y)
+    n = int(np.prod(tuple(y.shape)))
+    out, pout = call.cout((n,))
+    L.check(call.lib.ofdm_add_CFO(call.cin(y), n, float(CFO), int(Nfft), pout, call.flags), "add_CFO")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# synchronisation
+# ------------------------------------------------------------------------------------------------
+
+def AutoCorrFunction(RxSignal, WidthWindow, Nfft):
+    """T5/AutoCorrFunction.m:1-28 -> (AutoCorr row, TgPosition, FreqOffset).
+
+    Issues the reference's warning and returns TgPosition = 65 when no plateau is found."""
+    call = _Call(RxSignal)
+    n = int(np.prod(tuple(RxSignal.shape)))
+    W, Nfft = int(WidthWindow), int(Nfft)
+    n_out = max(n - W - Nfft, 0)
+    rho, prho = call.cout((n_out,))
+    pos = C.c_int64(0)
+    fo = C.c_double(0)
+    rc = L.check(call.lib.ofdm_AutoCorrFunction(call.cin(RxSignal), n, W, Nfft, prho, C.byref(pos), C.byref(fo),
+                                                call.flags), "AutoCorrFunction")
+    if rc == L.OFDM_SOFT_ACF_FALLBACK:
+        warnings.warn("AutoCorrFunction: problem locating the guard interval; TgPosition = 65")
+    return rho, int(pos.value), fo.value
+
+
+def remove_IFO(rx_signal, Nfft):
+    """T5/remove_IFO.m:1-11 -> (fixed_rx_signal, IFO)."""
+    call = _Call(rx_signal)
+    n = int(np.prod(tuple(rx_signal.shape)))
+    out, pout = call.cout((n,))
+    ifo = C.c_int(0)
+    L.check(call.lib.ofdm_remove_IFO(call.cin(rx_signal), n, int(Nfft), pout, C.byref(ifo), call.flags), "remove_IFO")
+    return out, ifo.value
+
+
+def fine_sync(rx_signal, pilotCarriers, pilotValues, time_desync, freq_desync, variant="T5", return_estimates=False):
+    """T5/fine_sync.m:1-45 (variant='T4' -> T4/fine_sync.m)."""
+    call = _Call(rx_signal)
+    nfft, ns = _shape2(rx_signal)
+    ppc, npil = call.idx(pilotCarriers)
+    out, pout = call.cout((nfft, ns))
+    tau, ph = C.c_double(0), C.c_double(0)
+    L.check(call.lib.ofdm_fine_sync(call.cin(rx_signal), nfft, ns, ppc, npil, call.cin(pilotValues),
+                                    int(bool(time_desync)), int(bool(freq_desync)), 1 if variant == "T4" else 0,
+                                    pout, C.byref(tau), C.byref(ph), call.flags), "fine_sync")
+    if return_estimates:
+        return out, tau.value, ph.value
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# channel estimation / equalisation
+# ------------------------------------------------------------------------------------------------
+
+def interpolate(H, pilot_loc, Nfft, method):
+    """T5/interpolate.m:1-24."""
+    call = _Call(H)
+    ploc, npil = call.idx(pilot_loc)
+    out, pout = call.cout((int(Nfft),))
+    L.check(call.lib.ofdm_interpolate(call.cin(H), ploc, npil, int(Nfft), str(method)[0].lower().encode(), pout,
+                                      call.flags), "interpolate")
+    return out
+
+
+def estimate_channel(rx_signal, allCarriers, pilotCarriers, pilotValues):
+    """T5/estimate_channel.m:1-9 -> (H_est row over allCarriers, Hest_at_pilots column)."""
+    call = _Call(rx_signal)
+    nfft, ns = _shape2(rx_signal)
+    pall, nall = call.idx(allCarriers)
+    ppc, npil = call.idx(pilotCarriers)
+    h, ph = call.cout((nall,))
+    hp, php = call.cout((npil,))
+    L.check(call.lib.ofdm_estimate_channel(call.cin(rx_signal), nfft, ns, pall, nall, ppc, npil,
+                                           call.cin(pilotValues), ph, php, call.flags), "estimate_channel")
+    return h, hp
+
+
+def equalize_signal(OFDM_demod, Hest, N_carrier):
+    """T5/equalize_signal.m:1-8."""
+    call = _Call(OFDM_demod)
+    nfft, ns = _shape2(OFDM_demod)
+    nc = int(N_carrier)
+    nh = int(np.prod(tuple(Hest.shape)))
+    if nh < nc:
+        raise OfdmError("equalize_signal: index exceeds the number of elements of Hest")
+    hflat = Hest.reshape(-1)[:nc] if _is_torch(Hest) else np.asarray(Hest).ravel()[:nc]
+    out, pout = call.cout((nfft, ns))
+    L.check(call.lib.ofdm_equalize_signal(call.cin(OFDM_demod), nfft, ns, call.cin(hflat), nc, pout, call.flags),
+            "equalize_signal")
+    return out
+
+
+def LS_CE(Y, Xp, pilot_loc, N_carrier):
+    """T5/LS_CE.m:1-34."""
+    call = _Call(Y)
+    nfft, ns = _shape2(Y)
+    ploc, npil = call.idx(pilot_loc)
+    out, pout = call.cout((int(N_carrier),))
+    L.check(call.lib.ofdm_LS_CE(call.cin(Y), nfft, ns, call.cin(Xp), ploc, npil, int(N_carrier), pout, call.flags),
+            "LS_CE")
+    return out
+
+
+def MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR):
+    """T5/MMSE_CE.m:1-39."""
+    call = _Call(Y)
+    nfft, ns = _shape2(Y)
+    ploc, npil = call.idx(pilot_loc)
+    nh = int(np.prod(tuple(h.shape)))
+    out, pout = call.cout((int(N_carrier),))
+    L.check(call.lib.ofdm_MMSE_CE(call.cin(Y), nfft, ns, call.cin(Xp), ploc, npil, int(N_carrier), call.cin(h), nh,
+                                  float(SNR), pout, call.flags), "MMSE_CE")
+    return out
+
+
+def sensing_matrix(pilotCarriers, Nfft, K, precision="fp64", device=None):
+    """S = P*F(:,1:K) of T5/Main_model_Task_5.m:182-190 in closed form (never builds dftmtx)."""
+    prim = (torch.zeros(1, dtype=torch.complex128 if precision == "fp64" else torch.complex64, device=device)
+            if device is not None else np.zeros(1, np.complex128 if precision == "fp64" else np.complex64))
+    call = _Call(prim)
+    ppc, npil = call.idx(pilotCarriers)
+    out, pout = call.cout((npil, int(K)))
+    L.check(call.lib.ofdm_sensing_matrix(ppc, npil, int(Nfft), int(K), pout, call.flags), "sensing_matrix")
+    return out
+
+
+def MP_estimate(Y, sensing_matrix_, Nfft, dominant_taps, return_picks=False):
+    """T5/MP_estimate.m:1-34 -> (H_MP row, h_impulse_est column)."""
+    call = _Call(Y)
+    npil, k = _shape2(sensing_matrix_)
+    T = int(dominant_taps)
+    H, pH = call.cout((int(Nfft),))
+    h, ph = call.cout((int(Nfft),))
+    picks = np.zeros(max(T, 1), dtype=np.int32)
+    L.check(call.lib.ofdm_MP_estimate(call.cin(Y), call.cin(sensing_matrix_), npil, k, int(Nfft), T, pH, ph,
+                                      picks.ctypes.data_as(C.c_void_p), call.flags), "MP_estimate")
+    if return_picks:
+        return H, h, picks[:T]
+    return H, h
+
+
+def OMP_estimate(Y, sensing_matrix_, Nfft, dominant_taps, SNR_dB=0.0):
+    """T5/OMP_estimate.m:1-37 -> (H_OMP row, h_impulse_est row, index)."""
+    call = _Call(Y)
+    npil, k = _shape2(sensing_matrix_)
+    T = int(dominant_taps)
+    H, pH = call.cout((int(Nfft),))
+    h, ph = call.cout((int(Nfft),))
+    index = np.zeros(max(T, 1), dtype=np.int32)
+    n_idx = C.c_int(0)
+    L.check(call.lib.ofdm_OMP_estimate(call.cin(Y), call.cin(sensing_matrix_), npil, k, int(Nfft), T, float(SNR_dB),
+                                       pH, ph, index.ctypes.data_as(C.c_void_p), C.byref(n_idx), call.flags),
+            "OMP_estimate")
+    return H, h, index[: n_idx.value].astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics
+# ------------------------------------------------------------------------------------------------
+
+def BER_func(Bit_Tx, Bit_Rx, return_count=False):
+    """T5/BER_func.m:1-7."""
+    call = _Call(Bit_Tx if _is_torch(Bit_Tx) else np.zeros(1, np.complex64), f64=False)
+    n = int(np.prod(tuple(Bit_Tx.shape)))
+    if int(np.prod(tuple(Bit_Rx.shape))) != n:
+        raise OfdmError("BER_func: arrays have incompatible sizes")
+    ne = C.c_int64(0)
+    L.check(call.lib.ofdm_BER_func(call.bits_in(Bit_Tx), call.bits_in(Bit_Rx), n, C.byref(ne), call.flags), "BER_func")
+    if return_count:
+        return ne.value
+    return ne.value / n
+
+
+def MER_func(IQ_RX, Constellation):
+    """T5/MER_func.m:1-26."""
+    call = _Call(IQ_RX)
+    n = int(np.prod(tuple(IQ_RX.shape)))
+    mer = C.c_double(0)
+    L.check(call.lib.ofdm_MER_func(call.cin(IQ_RX), n, _cstr(Constellation), C.byref(mer), call.flags), "MER_func")
+    return mer.value
+
+
+# ------------------------------------------------------------------------------------------------
+# fused Task-5 RX chain
+# ------------------------------------------------------------------------------------------------
+
+class RxPlan:
+    """Device-resident description of one Task-5 RX configuration (ofdm_rx_plan_create)."""
+
+    def __init__(self, Nfft, T_guard, N_symb, N_carrier, pilotCarriers, dataCarriers, pilotValues_col, K,
+                 dominant_taps, Constellation, precision="fp32", device=None):
+        self.lib = L.load()
+        init(-1 if device is None else int(device))
+        self.f64 = precision == "fp64"
+        self.Nfft, self.T_guard, self.N_symb, self.N_carrier = int(Nfft), int(T_guard), int(N_symb), int(N_carrier)
+        self.K, self.taps = int(K), int(dominant_taps)
+        self.bps = _bps(Constellation)
+        pc = np.ascontiguousarray(np.rint(np.asarray(pilotCarriers).ravel()).astype(np.int32))
+        dc = np.ascontiguousarray(np.rint(np.asarray(dataCarriers).ravel()).astype(np.int32))
+        pv = np.ascontiguousarray(np.asarray(pilotValues_col).ravel().astype(np.complex128 if self.f64 else np.complex64))
+        if pv.size != pc.size:
+            raise OfdmError("RxPlan: pilotValues_col must have numel(pilotCarriers) entries")
+        self.n_pilots, self.n_data = pc.size, dc.size
+        h = C.c_void_p(None)
+        L.check(self.lib.ofdm_rx_plan_create(C.byref(h), self.Nfft, self.T_guard, self.N_symb, self.N_carrier,
+                                             pc.ctypes.data_as(C.c_void_p), pc.size, dc.ctypes.data_as(C.c_void_p),
+                                             dc.size, pv.ctypes.data_as(C.c_void_p), self.K, self.taps,
+                                             _cstr(Constellation), L.OFDM_F64 if self.f64 else L.OFDM_F32),
+                "rx_plan_create")
+        self.handle = h
+        self.frame_bytes = int(self.lib.ofdm_rx_plan_frame_bytes(h))
+        self.frame_bits = self.n_data * self.N_symb * self.bps
+        self.frame_samples = (self.Nfft + self.T_guard) * self.N_symb
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ofdm_rx_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rx_chain_task5(plan: RxPlan, rx, ref_bits_packed=None, want_h=False, want_index=False):
+    """Fused demod -> OMP -> equalise -> payload -> demap -> BER over a batch of frames.
+
+    rx: [(Nfft+Tg)*N_symb, n_frames] complex (numpy -> host flavour, torch.cuda -> device flavour).
+    Returns dict(bits=[n_frames, frame_bytes] uint8 packed MSB-first (frame-major), errors=[n_frames] uint32 or None,
+    H=[N_carrier, n_frames] or None, index=[taps, n_frames] int32 or None)."""
+    call = _Call(rx, f64=plan.f64)
+    rows, nfr = _shape2(rx)
+    if rows != plan.frame_samples:
+        raise OfdmError("rx_chain_task5: rx must have (Nfft+T_guard)*N_symb rows")
+    flat_bits, pbits = call._out((plan.frame_bytes * nfr,), np.uint8, torch.uint8 if call.dev else None)
+    bits = flat_bits.reshape(nfr, plan.frame_bytes)
+    pref = None
+    errors, perr = None, None
+    if ref_bits_packed is not None:
+        ref = ref_bits_packed
+        if tuple(ref.shape) != (nfr, plan.frame_bytes):
+            raise OfdmError("rx_chain_task5: ref_bits_packed must be [n_frames, frame_bytes]")
+        ref = ref.contiguous().view(-1) if _is_torch(ref) else np.ascontiguousarray(ref).reshape(-1)
+        pref = call._flat(ref, np.uint8, torch.uint8 if call.dev else None)[0]
+        errors, perr = call._out((nfr,), np.uint32, torch.int32 if call.dev else None)
+    H, pH = (call.cout((plan.N_carrier, nfr)) if want_h else (None, None))
+    idx, pidx = (call._out((plan.taps, nfr), np.int32, torch.int32 if call.dev else None) if want_index else (None, None))
+    L.check(call.lib.ofdm_rx_chain_task5(plan.handle, call.cin(rx), nfr, pbits, pref, perr, pH, pidx, call.flags),
+            "rx_chain_task5")
+    return dict(bits=bits, errors=errors, H=H, index=idx)

@@ -1,0 +1,294 @@
+// Channel side: get_MP_channel_resp + the inline conv of the drivers, Noise (counter-based AWGN),
+// add_STO, add_CFO.
+#include "ofdm_common.hpp"
+
+namespace ofdm {
+
+int demod_device(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, bool f64);   // ofdm_modem.hip
+
+static unsigned ew_grid(int64_t total, int per_block = 256) {
+  int64_t b = (total + per_block - 1) / per_block;
+  int64_t cap = (int64_t)ctx().num_cu * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv(x,h.','full')(1:L) -- T5/Main_model_Task_5.m:126-127 as a sparse-tap gather FIR:
+// y[n] = sum_t a_t * x[n - d_t].  Zero taps of the dense h are skipped (exact: adds of +0).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct TapList {
+  const int32_t* delay;
+  const cx<T>* amp;
+  int n;
+};
+
+template <typename T>
+__global__ void fir_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int64_t len, TapList<T> taps) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < len; n += (int64_t)gridDim.x * blockDim.x) {
+    cx<T> acc = mk<T>(0, 0);
+    for (int t = 0; t < taps.n; ++t) {
+      const int64_t m = n - taps.delay[t];
+      if (m >= 0) acc = acc + x[m] * taps.amp[t];
+    }
+    y[n] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Noise -- T5/Noise.m:1-12.  Pass 1: sum |x|^2 (per-block partials in double, fixed order).
+// Pass 2 (one block): P -> sigma = sqrt(P / 10^(snr/10) / 2).  Pass 3: y = x + sigma*(n_re + i n_im)
+// with Philox4x32-10(counter = (i_lo, i_hi, stream, 0), key = seed) + Box-Muller on words 0,1.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void power_partial_kernel(const cx<T>* __restrict__ x, int64_t len, double* __restrict__ partial) {
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const cx<T> v = x[i];
+    s += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ double ws[16];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+// out[0] = sqrt(NoisePower/2) (per-component sigma), out[1] = sqrt(NoisePower) (N_var of Noise.m:11)
+__global__ void noise_sigma_kernel(const double* __restrict__ partial, int n_part, int64_t len, double snr_lin,
+                                   double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < n_part; ++i) s += partial[i];
+    const double p = s / (double)len;             // Noise.m:3
+    const double np = p / snr_lin;                // :5
+    out[0] = sqrt(np / 2.0);
+    out[1] = sqrt(np);
+  }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+template <typename T>
+__global__ void awgn_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int64_t len,
+                            const double* __restrict__ sigma, uint32_t k0, uint32_t k1, uint32_t stream) {
+  const double sg = sigma[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), stream, 0u, k0, k1, r);
+    // Box-Muller in double for both precisions (the draw is an INPUT of the chain; keeps the
+    // fp32 and fp64 modes on the same noise realisation up to the final rounding)
+    const double u0 = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
+    const double u1 = ((double)r[1] + 0.5) * 2.3283064365386963e-10;
+    const double rad = sqrt(-2.0 * log(u0));
+    double sn, cs;
+    sincospi(2.0 * u1, &sn, &cs);
+    const cx<T> v = x[i];
+    y[i] = mk<T>((T)((double)v.x + sg * rad * cs), (T)((double)v.y + sg * rad * sn));
+  }
+}
+
+// add_STO -- T5/add_STO.m:1-10
+template <typename T>
+__global__ void sto_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ out, int64_t len, int64_t n_sto) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = i + n_sto;
+    out[i] = (src >= 0 && src < len) ? y[src] : mk<T>(0, 0);
+  }
+}
+
+// add_CFO -- T5/add_CFO.m:1-8: y .* exp(2j*pi*CFO*n/Nfft).  The turn count CFO*n/Nfft is formed
+// in double and reduced to its fractional part before the sincos, for any stream length.
+template <typename T>
+__global__ void cfo_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ out, int64_t len, double cfo,
+                           double inv_nfft) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const double t = cfo * (double)i * inv_nfft;
+    const double fr = t - floor(t);
+    double sn, cs;
+    sincospi(2.0 * fr, &sn, &cs);
+    const cx<T> v = y[i];
+    out[i] = mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
+  }
+}
+
+// device-pointer helpers reused by the sync code
+int cfo_device(const void* y, void* out, int64_t len, double cfo, int nfft, bool f64) {
+  if (len == 0) return OFDM_OK;
+  if (f64)
+    hipLaunchKernelGGL(cfo_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)y, (c64*)out,
+                       len, cfo, 1.0 / (double)nfft);
+  else
+    hipLaunchKernelGGL(cfo_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)y, (c32*)out,
+                       len, cfo, 1.0 / (double)nfft);
+  return check_launch("cfo_kernel");
+}
+
+}  // namespace ofdm
+
+using namespace ofdm;
+
+extern "C" {
+
+int ofdm_get_MP_channel_resp(const double* taps, const double* taps_im, int n_taps, int nfft, void* h_out,
+                             int* h_len_out, void* H_out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(taps && n_taps > 0, "get_MP_channel_resp: empty tap list");
+  int max_delay = 0;
+  for (int i = 0; i < n_taps; ++i) {
+    const double d = taps[i];                                   // column 1 = delays (column-major)
+    OFDM_ARG(d >= 0 && d == std::floor(d) && d < (1 << 24), "get_MP_channel_resp: delay %g is not a non-negative integer", d);
+    if ((int)d > max_delay) max_delay = (int)d;                 // :4
+  }
+  const int hl = max_delay + 1;                                 // :5
+  std::vector<c64> h(hl, c64{0, 0});
+  for (int i = 0; i < n_taps; ++i)                              // :11-15 (later duplicates overwrite)
+    h[(int)taps[i]] = c64{taps[n_taps + i], taps_im ? taps_im[i] : 0.0};
+  if (h_len_out) *h_len_out = hl;
+  if (h_out) {
+    if (is_f64(flags)) memcpy(h_out, h.data(), sizeof(c64) * hl);
+    else for (int i = 0; i < hl; ++i) ((c32*)h_out)[i] = c32{(float)h[i].x, (float)h[i].y};
+  }
+  if (H_out) {
+    // fft(h, Nfft): zero-pad / truncate to Nfft (:18), on the device FFT
+    const bool f64 = is_f64(flags);
+    const size_t cs = f64 ? sizeof(c64) : sizeof(c32);
+    std::vector<c64> hp(nfft, c64{0, 0});
+    for (int i = 0; i < hl && i < nfft; ++i) hp[i] = h[i];
+    std::vector<c32> hp32;
+    const void* src = hp.data();
+    if (!f64) {
+      hp32.resize(nfft);
+      for (int i = 0; i < nfft; ++i) hp32[i] = c32{(float)hp[i].x, (float)hp[i].y};
+      src = hp32.data();
+    }
+    Stage st(OFDM_HOST | (flags & OFDM_F64));
+    const void* din; void* dout;
+    OFDM_TRY(st.in(src, cs * nfft, &din));
+    OFDM_TRY(st.out(H_out, cs * nfft, &dout));
+    OFDM_TRY(demod_device(din, dout, nfft, 1, 0, f64));
+    OFDM_TRY(st.finish());
+  }
+  return OFDM_OK;
+}
+
+int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void* y, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(len >= 0 && h_len > 0 && h, "channel_conv: bad sizes");
+  const bool f64 = is_f64(flags);
+  std::vector<int32_t> delays;
+  std::vector<c64> a64;
+  std::vector<c32> a32;
+  for (int d = 0; d < h_len; ++d) {
+    double re = f64 ? ((const c64*)h)[d].x : ((const c32*)h)[d].x;
+    double im = f64 ? ((const c64*)h)[d].y : ((const c32*)h)[d].y;
+    if (re != 0.0 || im != 0.0) {
+      delays.push_back(d);
+      a64.push_back(c64{re, im});
+      a32.push_back(c32{(float)re, (float)im});
+    }
+  }
+  Stage st(flags);
+  const void *dx, *dd, *da; void* dy;
+  OFDM_TRY(st.in(x, csize(flags) * (size_t)len, &dx));
+  OFDM_TRY(st.out(y, csize(flags) * (size_t)len, &dy));
+  const int nt = (int)delays.size();
+  if (nt == 0) {
+    if (len) OFDM_HIP(hipMemsetAsync(dy, 0, csize(flags) * (size_t)len, ctx().stream));
+    return st.finish();
+  }
+  OFDM_TRY(st.upload(delays.data(), sizeof(int32_t) * nt, &dd));
+  OFDM_TRY(st.upload(f64 ? (const void*)a64.data() : (const void*)a32.data(), csize(flags) * nt, &da));
+  if (len > 0) {
+    if (f64) {
+      TapList<double> tl{(const int32_t*)dd, (const c64*)da, nt};
+      hipLaunchKernelGGL(fir_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)dx,
+                         (c64*)dy, len, tl);
+    } else {
+      TapList<float> tl{(const int32_t*)dd, (const c32*)da, nt};
+      hipLaunchKernelGGL(fir_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)dx,
+                         (c32*)dy, len, tl);
+    }
+    OFDM_TRY(check_launch("fir_kernel"));
+  }
+  return st.finish();
+}
+
+int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_t stream, void* y,
+               double* n_var_out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(len >= 0, "Noise: negative length");
+  if (len == 0) { if (n_var_out) *n_var_out = NAN; return OFDM_OK; }
+  const bool f64 = is_f64(flags);
+  Stage st(flags);
+  const void* dx; void *dy, *dpart, *dsig;
+  OFDM_TRY(st.in(x, csize(flags) * (size_t)len, &dx));
+  OFDM_TRY(st.out(y, csize(flags) * (size_t)len, &dy));
+  const unsigned grid = ew_grid(len, 2048);
+  OFDM_TRY(st.scratch(sizeof(double) * grid, &dpart));
+  double sig_host[2] = {0, 0};
+  OFDM_TRY(st.fetch(n_var_out ? sig_host : nullptr, sizeof(sig_host), &dsig));
+  const double snr_lin = std::pow(10.0, snr_db / 10.0);
+  if (f64) hipLaunchKernelGGL(power_partial_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream, (const c64*)dx, len, (double*)dpart);
+  else hipLaunchKernelGGL(power_partial_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const c32*)dx, len, (double*)dpart);
+  OFDM_TRY(check_launch("power_partial_kernel"));
+  hipLaunchKernelGGL(noise_sigma_kernel, dim3(1), dim3(64), 0, ctx().stream, (const double*)dpart, (int)grid, len,
+                     snr_lin, (double*)dsig);
+  OFDM_TRY(check_launch("noise_sigma_kernel"));
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  if (f64) hipLaunchKernelGGL(awgn_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)dx, (c64*)dy, len, (const double*)dsig, k0, k1, stream);
+  else hipLaunchKernelGGL(awgn_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)dx, (c32*)dy, len, (const double*)dsig, k0, k1, stream);
+  OFDM_TRY(check_launch("awgn_kernel"));
+  OFDM_TRY(st.finish());
+  if (n_var_out) *n_var_out = sig_host[1];
+  return OFDM_OK;
+}
+
+int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(len >= 0, "add_STO: negative length");
+  Stage st(flags);
+  const void* dy; void* dout;
+  OFDM_TRY(st.in(y, csize(flags) * (size_t)len, &dy));
+  OFDM_TRY(st.out(out, csize(flags) * (size_t)len, &dout));
+  if (len > 0) {
+    if (is_f64(flags)) hipLaunchKernelGGL(sto_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)dy, (c64*)dout, len, n_sto);
+    else hipLaunchKernelGGL(sto_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)dy, (c32*)dout, len, n_sto);
+    OFDM_TRY(check_launch("sto_kernel"));
+  }
+  return st.finish();
+}
+
+int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(len >= 0 && nfft > 0, "add_CFO: bad sizes");
+  Stage st(flags);
+  const void* dy; void* dout;
+  OFDM_TRY(st.in(y, csize(flags) * (size_t)len, &dy));
+  OFDM_TRY(st.out(out, csize(flags) * (size_t)len, &dout));
+  OFDM_TRY(cfo_device(dy, dout, len, cfo, nfft, is_f64(flags)));
+  return st.finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""GPU parity: channel side (get_MP_channel_resp, conv, Noise, add_STO, add_CFO) and receiver
+synchronisation (AutoCorrFunction, remove_IFO, fine_sync) against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import crandn, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TAPS6 = np.array([[0, 1], [4, .8], [10, .6], [15, .4], [21, .2], [25, .1]])      # T5/Main_model_Task_5.m:112-119
+
+
+def test_get_mp_channel_resp(ofdm, oracle):
+    for nfft in (64, 2048, 4096):
+        h, H = ofdm.get_MP_channel_resp(TAPS6, nfft)
+        hw, Hw = oracle.get_MP_channel_resp(TAPS6, nfft)
+        assert np.array_equal(h, hw)
+        assert rel_l2(H, Hw) < 1e-14
+    # duplicate delay: the later row overwrites (get_MP_channel_resp.m:14)
+    taps = np.array([[0, 1], [3, .5], [3, .25]])
+    h, _ = ofdm.get_MP_channel_resp(taps, 64)
+    assert np.array_equal(h, [1, 0, 0, .25])
+
+
+@pytest.mark.parametrize("dt,tol", [(np.complex128, 1e-14), (np.complex64, 2e-7)])
+def test_channel_conv(ofdm, oracle, dt, tol):
+    rng = np.random.default_rng(1)
+    x = crandn(rng, 50000).astype(dt)
+    h, _ = oracle.get_MP_channel_resp(TAPS6, 2048)
+    assert rel_l2(ofdm.apply_channel(x, h), oracle.apply_channel(x.astype(np.complex128), h)) < tol
+    # dense complex 32-tap channel with delays up to 1000 (config C5 shape)
+    d = np.sort(rng.choice(1000, 32, replace=False))
+    hh = np.zeros(d[-1] + 1, complex); hh[d] = crandn(rng, 32)
+    assert rel_l2(ofdm.apply_channel(x, hh), oracle.apply_channel(x.astype(np.complex128), hh)) < tol
+    # shorter than the impulse response
+    assert rel_l2(ofdm.apply_channel(x[:10], h), oracle.apply_channel(x[:10].astype(np.complex128), h)) < tol
+
+
+def test_noise_matches_philox_restatement(ofdm, oracle):
+    rng = np.random.default_rng(2)
+    x = crandn(rng, 100000)
+    for snr in (0.0, 20.0):
+        y, nvar = ofdm.Noise(snr, x, seed=0x1234567890, stream=3)
+        nr, ni = oracle.awgn_philox(x.size, 0x1234567890, 3)
+        want, nvar_w = oracle.Noise(snr, x, nr, ni)
+        assert abs(nvar - nvar_w) < 1e-12 * nvar_w
+        assert rel_l2(y, want) < 1e-12
+    y32, _ = ofdm.Noise(20.0, x.astype(np.complex64), seed=0x1234567890, stream=3)
+    assert rel_l2(y32, want) < 2e-7
+    # measured SNR and independence of re/im
+    n = y - x
+    assert abs(10 * np.log10(np.mean(abs(x) ** 2) / np.mean(abs(n) ** 2)) - 20.0) < 0.1
+    assert abs(np.mean(n.real * n.imag)) < 1e-3 * np.mean(abs(n) ** 2) * 10
+    # different stream -> different draw
+    y2, _ = ofdm.Noise(20.0, x, seed=0x1234567890, stream=4)
+    assert rel_l2(y2, y) > 1e-3
+
+
+def test_add_sto_cfo(ofdm, oracle):
+    rng = np.random.default_rng(3)
+    x = crandn(rng, 10000)
+    for n in (0, 1, 37, 9999, 10000, 12000, -1, -500, -10000, -20000):
+        assert np.array_equal(ofdm.add_STO(x, n), oracle.add_STO(x, n)), n
+    for cfo in (0.0, 0.24, -3.0, 25.24, -17.5):
+        assert rel_l2(ofdm.add_CFO(x, cfo, 1024), oracle.add_CFO(x, cfo, 1024)) < 1e-12
+        assert rel_l2(ofdm.add_CFO(x.astype(np.complex64), cfo, 1024), oracle.add_CFO(x, cfo, 1024)) < 2e-7
+    # long stream: phase formed as frac(CFO*n/Nfft) in double (SURVEY section 7 hard part)
+    big = np.ones(3_000_000, dtype=np.complex64)
+    got = ofdm.add_CFO(big, 30.37, 4096)
+    nn = np.arange(big.size, dtype=np.float64)
+    want = np.exp(2j * np.pi * np.mod(30.37 * nn / 4096, 1.0))
+    assert np.max(np.abs(got - want)) < 5e-7
+
+
+def _t4_signal(oracle, nfft=1024, nc=400, ns=10, const="16QAM", seed=0):
+    """TX of T4/Main_model_Task_4.m (pilots +-4/3 max|dict| alternating)."""
+    rng = np.random.default_rng(seed)
+    pc, dc = oracle.pilot_layout_percent(nfft, nc, 15, 2)
+    D, bps = oracle.constellation_func(const)
+    amp = 4 / 3 * np.max(np.abs(D))
+    pv = np.where(np.arange(len(pc)) % 2 == 0, amp, -amp).astype(complex)
+    pv = np.repeat(pv[:, None], ns, axis=1)
+    bits = rng.integers(0, 2, len(dc) * ns * bps)
+    iq, _ = oracle.mapping(bits, const)
+    X = oracle.OFDM_map_carriers(iq, ns, nfft, dc, pc, pv)
+    tx = oracle.OFDM_modulator(X, nfft // 8).ravel(order="F")
+    return dict(tx=tx, pc=pc, dc=dc, pv=pv, bits=bits, X=X, nfft=nfft, tg=nfft // 8, ns=ns, const=const, nc=nc)
+
+
+@pytest.mark.parametrize("dt,tol", [(np.complex128, 1e-11), (np.complex64, 5e-6)])
+def test_autocorr_function(ofdm, oracle, dt, tol):
+    sg = _t4_signal(oracle)
+    rx = oracle.add_CFO(oracle.add_STO(sg["tx"], 37), 0.24, sg["nfft"])
+    rng = np.random.default_rng(1)
+    rx = rx + 0.02 * crandn(rng, rx.size)
+    rho, pos, fo = ofdm.AutoCorrFunction(rx.astype(dt), sg["tg"], sg["nfft"])
+    rho_w, pos_w, fo_w, ok = oracle.AutoCorrFunction(rx.astype(dt).astype(np.complex128), sg["tg"], sg["nfft"])
+    assert ok and rho.shape == rho_w.shape
+    assert np.max(np.abs(rho - rho_w)) < tol
+    assert pos == pos_w
+    assert abs(fo - fo_w) < max(tol, 1e-9)
+    assert abs(fo - 0.24) < 0.01
+
+
+def test_autocorr_fallback_and_errors(ofdm, oracle):
+    rng = np.random.default_rng(2)
+    noise = crandn(rng, 5000)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rho, pos, fo = ofdm.AutoCorrFunction(noise, 128, 1024)
+    assert pos == 65 and any("guard" in str(x.message) for x in w)      # AutoCorrFunction.m:21-24
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, pos_w, fo_w, ok = oracle.AutoCorrFunction(noise, 128, 1024)
+    assert not ok and pos_w == 65 and abs(fo - fo_w) < 1e-12
+    with pytest.raises(ofdm.OfdmError):
+        ofdm.AutoCorrFunction(noise[:1000], 128, 1024)
+
+
+def test_autocorr_only_one_run_takes_fallback(ofdm, oracle):
+    """A single plateau (no second run -> result(2) missing) must take the catch branch."""
+    sg = _t4_signal(oracle, ns=2)
+    rx = oracle.add_STO(sg["tx"], 300)[: 2 * 1152 - 200]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, pos, _ = ofdm.AutoCorrFunction(rx, sg["tg"], sg["nfft"])
+        _, pos_w, _, ok = oracle.AutoCorrFunction(rx, sg["tg"], sg["nfft"])
+    assert pos == pos_w and (not ok) == (pos == 65)
+
+
+@pytest.mark.parametrize("ifo", [0, 1, 7, 30])
+def test_remove_ifo(ofdm, oracle, ifo):
+    sg = _t4_signal(oracle)
+    rx = oracle.add_CFO(sg["tx"], ifo, sg["nfft"])
+    # remove_IFO.m relies on carrier 1 (DC) being occupied: window = samples Nfft+1..2Nfft
+    fixed, got = ofdm.remove_IFO(rx, sg["nfft"])
+    fixed_w, want = oracle.remove_IFO(rx, sg["nfft"])
+    assert got == want
+    assert rel_l2(fixed, fixed_w) < 1e-12
+    f32, got32 = ofdm.remove_IFO(rx.astype(np.complex64), sg["nfft"])
+    assert got32 == want and rel_l2(f32, fixed_w) < 5e-7
+    with pytest.raises(ofdm.OfdmError):
+        ofdm.remove_IFO(np.zeros(4096, complex), sg["nfft"])          # inds(1) on empty -> error
+    with pytest.raises(ofdm.OfdmError):
+        ofdm.remove_IFO(rx[:1500], sg["nfft"])
+
+
+@pytest.mark.parametrize("variant", ["T5", "T4"])
+@pytest.mark.parametrize("dt,tol", [(np.complex128, 1e-10), (np.complex64, 2e-5)])
+def test_fine_sync(ofdm, oracle, variant, dt, tol):
+    sg = _t4_signal(oracle)
+    nfft, tg, ns = sg["nfft"], sg["tg"], sg["ns"]
+    # residual timing offset of 4 samples + a common phase, symbol 1 blanked as T4:292-294 does
+    rx = oracle.add_STO(oracle.add_STO(sg["tx"], tg - 4 + nfft + tg), -(nfft + tg)) * np.exp(1j * 0.3)
+    X = oracle.OFDM_demodulator(rx.reshape((nfft + tg, ns), order="F"), tg).astype(dt)
+    got, tau, ph = ofdm.fine_sync(X, sg["pc"], sg["pv"], 1, 1, variant=variant, return_estimates=True)
+    want, tau_w, ph_w = oracle.fine_sync(X.astype(np.complex128), sg["pc"], sg["pv"], 1, 1, variant=variant)
+    assert abs(tau - tau_w) < tol and abs(ph - ph_w) < 100 * tol
+    assert abs(tau * nfft - 4.0) < 1e-3
+    assert rel_l2(got, want) < 200 * tol
+    # flags off -> identity
+    same = ofdm.fine_sync(X, sg["pc"], sg["pv"], 0, 0, variant=variant)
+    assert np.array_equal(same, X)
+
+
+def test_t4_chain_sync_to_bits(ofdm, oracle):
+    """Survey KAT (6): STO=37 noiseless, Nfft=1024, 68 pilots, 16QAM: TgPosition 1111 (CP start 1116),
+    tau*Nfft = 4, every error sits in the blanked symbol 1, BER ~ 1/ns * P(bit=1 pattern)."""
+    sg = _t4_signal(oracle, ns=50, seed=1)
+    nfft, tg, ns = sg["nfft"], sg["tg"], sg["ns"]
+    rx = ofdm.add_STO(sg["tx"], 37)
+    rho, pos, fo = ofdm.AutoCorrFunction(rx, tg, nfft)
+    assert pos == 1111
+    rx = ofdm.add_STO(ofdm.add_STO(rx, pos), -(nfft + tg))              # T4:292-294
+    X = ofdm.OFDM_demodulator(rx.reshape((nfft + tg, ns), order="F"), tg)
+    X, tau, _ = ofdm.fine_sync(X, sg["pc"], sg["pv"], 1, 0, return_estimates=True)
+    assert abs(tau * nfft - 4.0) < 1e-6
+    bits = ofdm.demapping(-1, ofdm.get_payload(X, sg["dc"]).ravel(order="F"), sg["const"])
+    per_sym = len(sg["dc"]) * 4
+    err = bits != sg["bits"]
+    assert not err[per_sym:].any()                                       # symbols 2..S error free
+    assert ofdm.BER_func(sg["bits"], bits) < 0.2                          # the driver's gate (T4:367)
