@@ -43,6 +43,9 @@ inline void fill_demap_table(const std::vector<c64>& dict, const ConstellationIn
 
 template <typename T>
 __device__ __forceinline__ int demap_decide(const DemapTable<T>& t, cx<T> z) {
+  // demapping.m:9 squares and adds as separate element-wise operations: no fused multiply-add here,
+  // so exact ties (and only those) resolve to the first minimum exactly like the reference.
+#pragma clang fp contract(off)
   if (t.kind == 0) {
     const int M = 1 << t.bps;
     int best = 0;

@@ -65,9 +65,11 @@ def test_demapping_bit_exact(ofdm, oracle, name, dt):
         assert np.array_equal(ofdm.demapping(3, iq[:50], name), want[: 50 * bps - 3])
 
 
-@pytest.mark.parametrize("name", ["QPSK", "16QAM", "64QAM", "256QAM", "8PSK"])
+@pytest.mark.parametrize("name", ["BPSK", "QPSK", "16QAM", "64QAM", "256QAM"])
 def test_demapping_ties_first_minimum_wins(ofdm, oracle, name):
-    """Exact ties (blanked carriers = 0+0i, points on decision boundaries)."""
+    """Exact ties (blanked carriers = 0+0i, points on decision boundaries).  8PSK is left out: its
+    table comes from exp(1i*k*pi/4), whose rounded points are not exactly equidistant from 0, so
+    the winner there depends on the last ulp of the host libm (parity unpinned)."""
     D, bps = oracle.constellation_func(name)
     lv = np.unique(np.round(D.real, 12))
     mids = (lv[:-1] + lv[1:]) / 2 if len(lv) > 1 else np.array([0.0])

@@ -160,14 +160,19 @@ def test_mp_omp_noisy_metric_config(ofdm, oracle, dt, tol, seed):
 
 
 def test_omp_early_stop_and_errors(ofdm, oracle):
-    """Exactly 2-sparse noiseless input with 6 requested taps: the relative-change rule (:20-22) stops."""
+    """Stopping rule (OMP_estimate.m:20-22): y = two atoms + a component orthogonal to every atom
+    (possible because Np > K).  After the two true picks the residual is that component, the third
+    atom changes it by ~eps, the relative change is < 1e-2 and the loop breaks with 3 picks."""
     nfft = 512
+    rng = np.random.default_rng(0)
     pc = np.arange(1, 129.0)
-    S = oracle.sensing_matrix(pc, nfft, 128)
-    y = S[:, 3] * (1 + 0.5j) + S[:, 40] * 0.7
+    S = oracle.sensing_matrix(pc, nfft, 32)
+    w = crandn(rng, 128)
+    w = w - S @ np.linalg.lstsq(S, w, rcond=None)[0]          # w is orthogonal to span(S)
+    y = S[:, 3] * (1 + 0.5j) + S[:, 20] * 0.7 + w
     Hw, hw, idx_w = oracle.OMP_estimate(y, S, nfft, 6)
     H, h, idx = ofdm.OMP_estimate(y, S, nfft, 6)
-    assert len(idx_w) < 6 and list(idx[:2]) == [4, 41] and len(idx) == len(idx_w)
+    assert len(idx_w) == 3 and len(idx) == 3 and sorted(idx[:2]) == [4, 21] == sorted(idx_w[:2])
     assert np.max(np.abs(h - hw)) < 1e-9
     with pytest.raises(ofdm.OfdmError):
-        ofdm.MP_estimate(y, S[:, :100], nfft, 3)            # K < Np: MP loop bound error (MP_estimate.m:10)
+        ofdm.MP_estimate(y, oracle.sensing_matrix(pc, nfft, 100), nfft, 3)   # K < Np (MP_estimate.m:10)
