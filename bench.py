@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: OFDM symbols/s through the full Task-5 RX chain (config M: Nfft=2048,
+Tg=256, N_carrier=512, comb 4, 64-QAM, OMP(6), frames of 14 symbols) on N MI355X GPUs.
+
+A "step" = one pass of the fused RX chain (ofdm_rx_chain_task5) over this rank's resident batch of
+synthetic frames (inputs already in HBM) + the end-of-tile SUM all-reduce of the error counters
+(RCCL, only when N > 1).  Weak scaling: every rank owns `--frames` frames; global frame ids (and
+therefore payload bits and noise) do not depend on the GPU count.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
+bytes of SURVEY.md section 8d / kernel time from HIP events on the launch stream) and `cpu_baseline`
+(the oracle = CPU restatement of the .m reference, timed on this box's host cores on a bounded
+sample of the same frames; NOT MATLAB).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_symbol(cfg, bps, csize):
+    """RX samples read once + packed decided bits written + reference bits read
+    + pilot column amortised over the frame.  Intermediates (X, H, equalised IQ) are not counted."""
+    nd, npil = len(cfg.dataCarriers), len(cfg.pilotCarriers)
+    return (cfg.Nfft + cfg.T_guard) * csize + 2 * nd * bps / 8.0 + npil * csize / cfg.N_symb
+
+
+def cpu_baseline(cfg, rx_host, pilots, bits, seconds, oracle):
+    """Oracle chain on host cores, single thread, frames processed until `seconds` elapsed."""
+    done, errs = 0, []
+    t0 = time.perf_counter()
+    while done < rx_host.shape[1] and (time.perf_counter() - t0) < seconds:
+        r = oracle.rx_chain_task5(rx_host[:, done:done + 1], cfg.Nfft, cfg.T_guard, cfg.N_carrier, cfg.pilotCarriers,
+                                  cfg.dataCarriers, pilots, cfg.K, cfg.dominant_taps, cfg.Constellation,
+                                  ref_bits=bits[done:done + 1])
+        errs.append(int(r["errors"][0]))
+        done += 1
+    dt = time.perf_counter() - t0
+    return done, dt, np.array(errs, dtype=np.int64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8192, help="frames resident per GPU (8192 = 2.1 GB fp32 input)")
+    ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-frames", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ofdm_course_amd as ofdm
+    from ofdm_course_amd import frames as fr
+
+    ofdm.init(local_rank)
+    cfg = fr.config_M()
+    _, bps = ofdm.constellation_func(cfg.Constellation)
+    F = args.frames
+    f0 = rank * F
+    data = fr.make_frames(cfg, ofdm, F, seed=1, precision=args.precision, device=dev, frame0=f0)
+    plan = fr.make_plan(cfg, ofdm, precision=args.precision, device=local_rank)
+    ref = torch.from_numpy(data["packed"]).to(dev)
+    rx = data["rx"]
+    torch.cuda.synchronize()
+    frame_bits = data["bits"].shape[1]
+    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def step():
+        out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
+        return out
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+        if world > 1:
+            counters[0] = out["errors"].sum()
+            counters[1] = F * frame_bits
+            dist.all_reduce(counters)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        out = step()
+        ev[i][1].record()
+        if world > 1:
+            counters[0] = out["errors"].sum()
+            counters[1] = F * frame_bits
+            dist.all_reduce(counters)          # the sweep's only collective: SUM of the error / bit counters
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    if world == 1:
+        counters[0] = out["errors"].sum()
+        counters[1] = F * frame_bits
+    tot_err, tot_bits = int(counters[0].item()), int(counters[1].item())
+
+    if rank == 0:
+        sym_per_step = F * cfg.N_symb * world
+        value = sym_per_step * args.steps / elapsed
+        csize = 16 if args.precision == "fp64" else 8
+        b_sym = algorithmic_bytes_per_symbol(cfg, bps, csize)
+        achieved = b_sym * F * cfg.N_symb / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "OFDM sym/s full Task-5 RX (Nfft=2048, 64-QAM, OMP)",
+            "value": value, "unit": "OFDM symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
+            "config": {"workload": "M: Nfft=2048 Tg=256 N_carrier=512 comb=4 (128 pilots, K=128) 64QAM OMP(6 taps) "
+                                   "6-tap channel 20 dB, frames of 14 symbols",
+                       "frames_per_gpu": F, "symbols_per_step": sym_per_step, "sharding": f"frames x{world}"},
+            "ber": tot_err / max(tot_bits, 1),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rx_chain_kernel", "kernel_ms": kernel_ms, "bytes_per_symbol": b_sym},
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import ofdm_oracle as oracle
+            ncpu = min(args.cpu_frames, F)
+            rx_host = rx.t()[:ncpu].contiguous().cpu().numpy().T.astype(np.complex128)
+            done, dt, errs = cpu_baseline(cfg, rx_host, data["pilots"], data["bits"], args.cpu_seconds, oracle)
+            gpu_errs = out["errors"][:done].cpu().numpy().astype(np.int64)
+            res["cpu_baseline"] = {
+                "value": done * cfg.N_symb / dt, "unit": "OFDM symbols/s", "cores": 1, "kind": "port",
+                "sample": f"first {done} of the {F} benchmark frames ({done * cfg.N_symb} symbols), numpy float64 "
+                          f"oracle (CPU restatement of the .m reference, not MATLAB), {dt:.1f} s, host has "
+                          f"{os.cpu_count()} cores"}
+            res["ber_match"] = {"frames": int(done), "gpu_errors": int(gpu_errs.sum()), "oracle_errors": int(errs.sum()),
+                                "max_abs_diff_per_frame": int(np.max(np.abs(gpu_errs - errs))) if done else 0}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,10 +103,17 @@ int ofdm_get_MP_channel_resp(const double* taps, const double* taps_im, int n_ta
                              void* h_out, int* h_len_out, void* H_out, int flags);
 /* conv(x,h.','full')(1:len) -- T5/Main_model_Task_5.m:126-127.  h is a HOST complex array. */
 int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void* y, int flags);
+/* Batch of independent streams (one Monte-Carlo frame each, T5/Task5_part2.m:148-152): x/y are
+ * [frame_len x n_frames] column-major, every frame starts from silence. */
+int ofdm_channel_conv_frames(const void* x, int64_t frame_len, int64_t n_frames, const void* h, int h_len,
+                             void* y, int flags);
 /* T5/Noise.m:1-12 with a counter-based generator (Philox4x32-10 + Box-Muller, seed/stream):
  * y = x + sqrt(P/snr/2)*(n_re + i n_im).  *n_var_out = sqrt(NoisePower) (Noise.m:11). */
 int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_t stream,
                void* y, double* n_var_out, int flags);
+/* One Noise() call per frame (power measured per frame, Philox stream = stream0 + frame). */
+int ofdm_Noise_frames(double snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
+                      uint32_t stream0, void* y, int flags);
 /* T5/add_STO.m:1-10 and T5/add_CFO.m:1-8. */
 int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags);
 int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, int flags);

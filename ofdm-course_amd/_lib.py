@@ -45,6 +45,8 @@ SIGNATURES = {
     "ofdm_get_MP_channel_resp": [_vp, _vp, _i, _i, _vp, _pi, _vp, _i],
     "ofdm_channel_conv": [_vp, _i64, _vp, _i, _vp, _i],
     "ofdm_Noise": [_d, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _pd, _i],
+    "ofdm_channel_conv_frames": [_vp, _i64, _i64, _vp, _i, _vp, _i],
+    "ofdm_Noise_frames": [_d, _vp, _i64, _i64, C.c_uint64, C.c_uint32, _vp, _i],
     "ofdm_add_STO": [_vp, _i64, _i64, _vp, _i],
     "ofdm_add_CFO": [_vp, _i64, _d, _i, _vp, _i],
     "ofdm_AutoCorrFunction": [_vp, _i64, _i, _i, _vp, _pi64, _pd, _i],

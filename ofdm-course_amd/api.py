@@ -33,7 +33,7 @@ __all__ = [
     "OfdmError", "init", "shutdown", "constellation_func", "mapping", "demapping", "Scrambler",
     "DeScrambler", "Scrambler_frames", "DeScrambler_frames", "OFDM_map_carriers", "get_payload",
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
-    "add_CFO", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
+    "add_CFO", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
     "MER_func", "RxPlan", "rx_chain_task5", "DEFAULT_REGISTER",
 ]
@@ -354,6 +354,27 @@ def Noise(SNR, IQ_TX, seed=0, stream=0):
     L.check(call.lib.ofdm_Noise(float(SNR), call.cin(IQ_TX), n, int(seed), int(stream), pout, C.byref(nv), call.flags),
             "Noise")
     return out, nv.value
+
+
+def apply_channel_frames(x, h):
+    """apply_channel on every column of x = [frame_len, n_frames] independently (Monte-Carlo frames)."""
+    call = _Call(x)
+    flen, nfr = _shape2(x)
+    hh = np.ascontiguousarray(np.asarray(h.cpu().numpy() if _is_torch(h) else h).ravel().astype(call.cdt))
+    out, pout = call.cout((flen, nfr))
+    L.check(call.lib.ofdm_channel_conv_frames(call.cin(x), flen, nfr, hh.ctypes.data_as(C.c_void_p), hh.size, pout,
+                                              call.flags), "channel_conv_frames")
+    return out
+
+
+def Noise_frames(SNR, IQ_TX, seed=0, stream0=0):
+    """Noise() applied per column of IQ_TX = [frame_len, n_frames]; column f uses Philox stream stream0+f."""
+    call = _Call(IQ_TX)
+    flen, nfr = _shape2(IQ_TX)
+    out, pout = call.cout((flen, nfr))
+    L.check(call.lib.ofdm_Noise_frames(float(SNR), call.cin(IQ_TX), flen, nfr, int(seed), int(stream0), pout,
+                                       call.flags), "Noise_frames")
+    return out
 
 
 def add_STO(y, nSTO):

@@ -25,13 +25,16 @@ struct TapList {
   int n;
 };
 
+// frame_len > 0: the stream is a batch of independent frames (each starts from silence).
 template <typename T>
-__global__ void fir_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int64_t len, TapList<T> taps) {
+__global__ void fir_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int64_t len, int64_t frame_len,
+                           TapList<T> taps) {
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < len; n += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t in_frame = n % frame_len;
     cx<T> acc = mk<T>(0, 0);
     for (int t = 0; t < taps.n; ++t) {
-      const int64_t m = n - taps.delay[t];
-      if (m >= 0) acc = acc + x[m] * taps.amp[t];
+      const int64_t d = taps.delay[t];
+      if (in_frame - d >= 0) acc = acc + x[n - d] * taps.amp[t];
     }
     y[n] = acc;
   }
@@ -42,8 +45,10 @@ __global__ void fir_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, i
 // Pass 2 (one block): P -> sigma = sqrt(P / 10^(snr/10) / 2).  Pass 3: y = x + sigma*(n_re + i n_im)
 // with Philox4x32-10(counter = (i_lo, i_hi, stream, 0), key = seed) + Box-Muller on words 0,1.
 // ---------------------------------------------------------------------------------------------
+// grid = (blocks_per_frame, n_frames); partial[frame * blocks_per_frame + block]
 template <typename T>
-__global__ void power_partial_kernel(const cx<T>* __restrict__ x, int64_t len, double* __restrict__ partial) {
+__global__ void power_partial_kernel(const cx<T>* __restrict__ xall, int64_t len, double* __restrict__ partial) {
+  const cx<T>* x = xall + (int64_t)blockIdx.y * len;
   double s = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
     const cx<T> v = x[i];
@@ -56,20 +61,21 @@ __global__ void power_partial_kernel(const cx<T>* __restrict__ x, int64_t len, d
   if (threadIdx.x == 0) {
     double t = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
-    partial[blockIdx.x] = t;
+    partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
 }
 
 // out[0] = sqrt(NoisePower/2) (per-component sigma), out[1] = sqrt(NoisePower) (N_var of Noise.m:11)
 __global__ void noise_sigma_kernel(const double* __restrict__ partial, int n_part, int64_t len, double snr_lin,
-                                   double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+                                   double* __restrict__ out, int64_t n_frames) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n_frames) {
     double s = 0;
-    for (int i = 0; i < n_part; ++i) s += partial[i];
+    for (int i = 0; i < n_part; ++i) s += partial[f * n_part + i];
     const double p = s / (double)len;             // Noise.m:3
     const double np = p / snr_lin;                // :5
-    out[0] = sqrt(np / 2.0);
-    out[1] = sqrt(np);
+    out[2 * f] = sqrt(np / 2.0);
+    out[2 * f + 1] = sqrt(np);
   }
 }
 
@@ -90,10 +96,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
+// grid.y = frame; frame f uses Philox stream `stream0 + f` and its own sigma
 template <typename T>
-__global__ void awgn_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int64_t len,
-                            const double* __restrict__ sigma, uint32_t k0, uint32_t k1, uint32_t stream) {
-  const double sg = sigma[0];
+__global__ void awgn_kernel(const cx<T>* __restrict__ xall, cx<T>* __restrict__ yall, int64_t len,
+                            const double* __restrict__ sigma, uint32_t k0, uint32_t k1, uint32_t stream0) {
+  const cx<T>* x = xall + (int64_t)blockIdx.y * len;
+  cx<T>* y = yall + (int64_t)blockIdx.y * len;
+  const double sg = sigma[2 * blockIdx.y];
+  const uint32_t stream = stream0 + blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t r[4];
     philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), stream, 0u, k0, k1, r);
@@ -193,9 +203,10 @@ int ofdm_get_MP_channel_resp(const double* taps, const double* taps_im, int n_ta
   return OFDM_OK;
 }
 
-int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void* y, int flags) {
+static int conv_common(const void* x, int64_t frame_len, int64_t n_frames, const void* h, int h_len, void* y, int flags) {
   OFDM_TRY(ensure_init());
-  OFDM_ARG(len >= 0 && h_len > 0 && h, "channel_conv: bad sizes");
+  OFDM_ARG(frame_len >= 0 && n_frames >= 0 && h_len > 0 && h, "channel_conv: bad sizes");
+  const int64_t len = frame_len * n_frames;
   const bool f64 = is_f64(flags);
   std::vector<int32_t> delays;
   std::vector<c64> a64;
@@ -224,45 +235,70 @@ int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void
     if (f64) {
       TapList<double> tl{(const int32_t*)dd, (const c64*)da, nt};
       hipLaunchKernelGGL(fir_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)dx,
-                         (c64*)dy, len, tl);
+                         (c64*)dy, len, frame_len, tl);
     } else {
       TapList<float> tl{(const int32_t*)dd, (const c32*)da, nt};
       hipLaunchKernelGGL(fir_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)dx,
-                         (c32*)dy, len, tl);
+                         (c32*)dy, len, frame_len, tl);
     }
     OFDM_TRY(check_launch("fir_kernel"));
   }
   return st.finish();
 }
 
-int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_t stream, void* y,
-               double* n_var_out, int flags) {
+int ofdm_channel_conv(const void* x, int64_t len, const void* h, int h_len, void* y, int flags) {
+  return conv_common(x, len, 1, h, h_len, y, flags);
+}
+int ofdm_channel_conv_frames(const void* x, int64_t frame_len, int64_t n_frames, const void* h, int h_len, void* y,
+                             int flags) {
+  return conv_common(x, frame_len, n_frames, h, h_len, y, flags);
+}
+
+static int noise_common(double snr_db, const void* x, int64_t len, int64_t n_frames, uint64_t seed, uint32_t stream,
+                        void* y, double* n_var_out, int flags) {
   OFDM_TRY(ensure_init());
-  OFDM_ARG(len >= 0, "Noise: negative length");
-  if (len == 0) { if (n_var_out) *n_var_out = NAN; return OFDM_OK; }
+  OFDM_ARG(len >= 0 && n_frames >= 0 && n_frames < 65536 * 1024, "Noise: bad sizes");
+  if (len == 0 || n_frames == 0) { if (n_var_out) *n_var_out = NAN; return OFDM_OK; }
   const bool f64 = is_f64(flags);
   Stage st(flags);
   const void* dx; void *dy, *dpart, *dsig;
-  OFDM_TRY(st.in(x, csize(flags) * (size_t)len, &dx));
-  OFDM_TRY(st.out(y, csize(flags) * (size_t)len, &dy));
-  const unsigned grid = ew_grid(len, 2048);
-  OFDM_TRY(st.scratch(sizeof(double) * grid, &dpart));
+  OFDM_TRY(st.in(x, csize(flags) * (size_t)len * n_frames, &dx));
+  OFDM_TRY(st.out(y, csize(flags) * (size_t)len * n_frames, &dy));
+  unsigned bpf = (unsigned)std::min<int64_t>((len + 2047) / 2048, n_frames > 1 ? 16 : 2048);   // blocks per frame
+  if (bpf < 1) bpf = 1;
+  OFDM_ARG(n_frames <= 65535, "Noise: at most 65535 frames per call");
+  OFDM_TRY(st.scratch(sizeof(double) * (size_t)bpf * n_frames, &dpart));
   double sig_host[2] = {0, 0};
-  OFDM_TRY(st.fetch(n_var_out ? sig_host : nullptr, sizeof(sig_host), &dsig));
+  const bool want = n_var_out && n_frames == 1;
+  if (want) OFDM_TRY(st.fetch(sig_host, sizeof(sig_host), &dsig));
+  else OFDM_TRY(st.scratch(sizeof(double) * 2 * (size_t)n_frames, &dsig));
   const double snr_lin = std::pow(10.0, snr_db / 10.0);
-  if (f64) hipLaunchKernelGGL(power_partial_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream, (const c64*)dx, len, (double*)dpart);
-  else hipLaunchKernelGGL(power_partial_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const c32*)dx, len, (double*)dpart);
+  const dim3 pgrid(bpf, (unsigned)n_frames);
+  if (f64) hipLaunchKernelGGL(power_partial_kernel<double>, pgrid, dim3(256), 0, ctx().stream, (const c64*)dx, len, (double*)dpart);
+  else hipLaunchKernelGGL(power_partial_kernel<float>, pgrid, dim3(256), 0, ctx().stream, (const c32*)dx, len, (double*)dpart);
   OFDM_TRY(check_launch("power_partial_kernel"));
-  hipLaunchKernelGGL(noise_sigma_kernel, dim3(1), dim3(64), 0, ctx().stream, (const double*)dpart, (int)grid, len,
-                     snr_lin, (double*)dsig);
+  hipLaunchKernelGGL(noise_sigma_kernel, dim3(cdiv_u(n_frames, 64)), dim3(64), 0, ctx().stream, (const double*)dpart,
+                     (int)bpf, len, snr_lin, (double*)dsig, n_frames);
   OFDM_TRY(check_launch("noise_sigma_kernel"));
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  if (f64) hipLaunchKernelGGL(awgn_kernel<double>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c64*)dx, (c64*)dy, len, (const double*)dsig, k0, k1, stream);
-  else hipLaunchKernelGGL(awgn_kernel<float>, dim3(ew_grid(len)), dim3(256), 0, ctx().stream, (const c32*)dx, (c32*)dy, len, (const double*)dsig, k0, k1, stream);
+  unsigned abx = (unsigned)std::min<int64_t>((len + 255) / 256, n_frames > 1 ? 64 : (int64_t)ctx().num_cu * 8);
+  if (abx < 1) abx = 1;
+  const dim3 agrid(abx, (unsigned)n_frames);
+  if (f64) hipLaunchKernelGGL(awgn_kernel<double>, agrid, dim3(256), 0, ctx().stream, (const c64*)dx, (c64*)dy, len, (const double*)dsig, k0, k1, stream);
+  else hipLaunchKernelGGL(awgn_kernel<float>, agrid, dim3(256), 0, ctx().stream, (const c32*)dx, (c32*)dy, len, (const double*)dsig, k0, k1, stream);
   OFDM_TRY(check_launch("awgn_kernel"));
   OFDM_TRY(st.finish());
-  if (n_var_out) *n_var_out = sig_host[1];
+  if (want) *n_var_out = sig_host[1];
   return OFDM_OK;
+}
+
+int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_t stream, void* y,
+               double* n_var_out, int flags) {
+  return noise_common(snr_db, x, len, 1, seed, stream, y, n_var_out, flags);
+}
+int ofdm_Noise_frames(double snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
+                      uint32_t stream0, void* y, int flags) {
+  return noise_common(snr_db, x, frame_len, n_frames, seed, stream0, y, nullptr, flags);
 }
 
 int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags) {

@@ -99,12 +99,12 @@ def unpack_bits(packed: np.ndarray, n_bits: int) -> np.ndarray:
     return np.unpackbits(p, axis=1, bitorder="big")[:, :n_bits]
 
 
-def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise=True):
+def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise=True, frame0=0):
     """Synthetic RX frames through the product's own TX + channel kernels.
 
     Returns dict(rx=[frame_samples, n_frames] complex (torch.cuda if device is not None else numpy),
     bits=[n_frames, frame_bits] uint8, packed=[n_frames, frame_bytes] uint8, pilots=[Np] complex).
-    Frame f draws its payload from PCG64(seed, f) and its noise from Philox key `seed`, stream f
+    Global frame g = frame0 + f draws its payload from PCG64(seed, g) and its noise from Philox key `seed`, stream g
     (each frame is one Noise() call, i.e. the SNR is relative to that frame's measured power, as in
     T5/Task5_part2.m:134) -- so results do not depend on how frames are sharded over GPUs.
     """
@@ -112,10 +112,11 @@ def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise
     nb = frame_bits(cfg, api)
     bits = np.empty((n_frames, nb), dtype=np.uint8)
     for f in range(n_frames):
-        bits[f] = np.random.Generator(np.random.PCG64([seed, f])).integers(0, 2, nb, dtype=np.uint8)
+        bits[f] = np.random.Generator(np.random.PCG64([seed, frame0 + f])).integers(0, 2, nb, dtype=np.uint8)
     pv_col = pilot_column(cfg, api)
     pv = np.repeat(pv_col[:, None], cfg.N_symb * n_frames, axis=1)
     h, _ = api.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+    CH = 4096                                          # frames per Noise_frames call (<= 65535)
     if device is not None:
         import torch
         tb = torch.from_numpy(bits.reshape(-1)).to(device)
@@ -124,26 +125,27 @@ def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise
                                   torch.from_numpy(np.ascontiguousarray(pv.T.astype(cdt))).to(device).t())
         tx = api.OFDM_modulator(X, cfg.T_guard)
         del X, iq
-        cols = []
-        flat = tx.t().contiguous().view(n_frames, cfg.frame_samples)
-        for f in range(n_frames):
-            y = api.apply_channel(flat[f], h)          # per-frame stream (transient inside the first CP)
-            if noise:
-                y, _ = api.Noise(cfg.SNR_dB, y, seed=seed, stream=f)
-            cols.append(y)
-        rx = torch.stack(cols, dim=0).t()               # [frame_samples, n_frames], column-major storage
+        flat = tx.t().contiguous().view(n_frames, cfg.frame_samples).t()     # [frame_samples, n_frames]
     else:
         iq, _ = api.mapping(bits.reshape(-1), cfg.Constellation, precision=precision)
         X = api.OFDM_map_carriers(iq, cfg.N_symb * n_frames, cfg.Nfft, cfg.dataCarriers, cfg.pilotCarriers,
                                   pv.astype(cdt))
         tx = api.OFDM_modulator(X, cfg.T_guard)
         flat = np.asarray(tx).reshape((cfg.frame_samples, n_frames), order="F")
-        rx = np.empty((cfg.frame_samples, n_frames), dtype=cdt, order="F")
-        for f in range(n_frames):
-            y = api.apply_channel(flat[:, f], h)
-            if noise:
-                y, _ = api.Noise(cfg.SNR_dB, y, seed=seed, stream=f)
-            rx[:, f] = y
+    # per-frame stream: the conv transient of a frame falls inside its first CP
+    rx = api.apply_channel_frames(flat, h)
+    if noise:
+        if n_frames <= CH:
+            rx = api.Noise_frames(cfg.SNR_dB, rx, seed=seed, stream0=frame0)
+        else:
+            parts = []
+            for f0 in range(0, n_frames, CH):
+                parts.append(api.Noise_frames(cfg.SNR_dB, rx[:, f0:f0 + CH], seed=seed, stream0=frame0 + f0))
+            if device is not None:
+                import torch
+                rx = torch.cat([p.t() for p in parts], dim=0).t()
+            else:
+                rx = np.concatenate(parts, axis=1)
     return dict(rx=rx, bits=bits, packed=pack_bits(bits), pilots=pv_col)
 
 
