@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8192, help="frames resident per GPU (8192 = 2.1 GB fp32 input)")
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-frames", type=int, default=64)
+    ap.add_argument("--cpu-frames", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
