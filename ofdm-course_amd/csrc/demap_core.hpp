@@ -21,7 +21,34 @@ struct DemapTable {
   cx<T> pts[8];
   T axis_i[16];
   T axis_q[16];
+  // square QAM slicer: decision thresholds between neighbouring levels in ascending order of the
+  // coordinate (I axis: level rank l <-> code gray(l); Q axis: rank l <-> code gray(L-1-l))
+  T thr_i[15];
+  T thr_q[15];
 };
+
+inline int gray_encode(int l) { return l ^ (l >> 1); }
+
+// Largest x in [lo, hi] for which the reference's rule still prefers the LOWER level:
+//   upper preferred  <=>  (x-hi)^2 < (x-lo)^2  ||  ((x-hi)^2 == (x-lo)^2 && upper_wins_tie)
+// evaluated in T with separate multiply and add exactly like demapping.m:9, located by bisection
+// down to adjacent floating-point numbers.  The device then decides with `x > threshold`.
+template <typename T>
+inline T demap_threshold(T lo, T hi, bool upper_wins_tie) {
+#pragma clang fp contract(off)
+  auto upper = [&](T x) {
+    volatile T dl = (x - lo) * (x - lo);
+    volatile T du = (x - hi) * (x - hi);
+    return du < dl || (du == dl && upper_wins_tie);
+  };
+  T a = lo, b = hi;                       // upper(a) false, upper(b) true
+  for (int it = 0; it < 4096; ++it) {
+    const T m = a + (b - a) / 2;
+    if (!(m > a && m < b)) break;         // a and b are adjacent
+    if (upper(m)) b = m; else a = m;
+  }
+  return a;
+}
 
 template <typename T>
 inline void fill_demap_table(const std::vector<c64>& dict, const ConstellationInfo& info, DemapTable<T>& t) {
@@ -38,35 +65,69 @@ inline void fill_demap_table(const std::vector<c64>& dict, const ConstellationIn
       t.axis_i[c] = (T)dict[c << ba].x;   // any Q code: the I level only depends on the I code
       t.axis_q[c] = (T)dict[c].y;
     }
+    for (int l = 0; l + 1 < L; ++l) {
+      // first-minimum rule: on an exact tie the smaller CODE wins
+      const int ci_lo = gray_encode(l), ci_hi = gray_encode(l + 1);
+      t.thr_i[l] = demap_threshold<T>(t.axis_i[ci_lo], t.axis_i[ci_hi], ci_hi < ci_lo);
+      const int cq_lo = gray_encode(L - 1 - l), cq_hi = gray_encode(L - 2 - l);
+      t.thr_q[l] = demap_threshold<T>(t.axis_q[cq_lo], t.axis_q[cq_hi], cq_hi < cq_lo);
+    }
   }
+  for (int l = (info.kind == 1 ? (1 << info.bits_per_axis) - 1 : 0); l < 15; ++l) t.thr_i[l] = t.thr_q[l] = T(0);
 }
 
+// Square QAM: the squared distance separates per axis and is unimodal along an axis, so the
+// per-axis first-minimum search equals "count the decision thresholds below the coordinate".  The
+// thresholds come from demap_threshold (host), which evaluates the reference's own comparison, ties
+// included.  All table indices are compile-time constants (scalar registers, no table loads).
+template <typename T, int BA>
+__device__ __forceinline__ int demap_square(const DemapTable<T>& t, cx<T> z) {
+  constexpr int L = 1 << BA;
+  int li = 0, lq = 0;
+#pragma unroll
+  for (int c = 0; c < L - 1; ++c) {
+    li += (z.x > t.thr_i[c]) ? 1 : 0;
+    lq += (z.y > t.thr_q[c]) ? 1 : 0;
+  }
+  if (z.y != z.y) lq = L - 1;              // NaN: every distance is NaN and `min` returns index 1
+  const int ci = li ^ (li >> 1);
+  const int lr = (L - 1) - lq;
+  const int cq = lr ^ (lr >> 1);
+  return (ci << BA) | cq;
+}
+
+template <typename T, int M>
+__device__ __forceinline__ int demap_table(const DemapTable<T>& t, cx<T> z) {
+#pragma clang fp contract(off)
+  int best = 0;
+  T bd = (z.x - t.pts[0].x) * (z.x - t.pts[0].x) + (z.y - t.pts[0].y) * (z.y - t.pts[0].y);
+#pragma unroll
+  for (int i = 1; i < M; ++i) {
+    const T d = (z.x - t.pts[i].x) * (z.x - t.pts[i].x) + (z.y - t.pts[i].y) * (z.y - t.pts[i].y);
+    const bool l = d < bd;
+    bd = l ? d : bd;
+    best = l ? i : best;
+  }
+  return best;
+}
+
+// demapping.m:9 squares and adds as separate element-wise operations: no fused multiply-add
+// (contract off), so exact ties (and only those) resolve to the first minimum like the reference.
 template <typename T>
 __device__ __forceinline__ int demap_decide(const DemapTable<T>& t, cx<T> z) {
-  // demapping.m:9 squares and adds as separate element-wise operations: no fused multiply-add here,
-  // so exact ties (and only those) resolve to the first minimum exactly like the reference.
-#pragma clang fp contract(off)
   if (t.kind == 0) {
-    const int M = 1 << t.bps;
-    int best = 0;
-    T bd = (z.x - t.pts[0].x) * (z.x - t.pts[0].x) + (z.y - t.pts[0].y) * (z.y - t.pts[0].y);
-    for (int i = 1; i < M; ++i) {
-      T d = (z.x - t.pts[i].x) * (z.x - t.pts[i].x) + (z.y - t.pts[i].y) * (z.y - t.pts[i].y);
-      if (d < bd) { bd = d; best = i; }
+    switch (t.bps) {
+      case 1: return demap_table<T, 2>(t, z);
+      case 2: return demap_table<T, 4>(t, z);
+      default: return demap_table<T, 8>(t, z);
     }
-    return best;
   }
-  const int L = 1 << t.bits_per_axis;
-  int bi = 0, bq = 0;
-  T di = (z.x - t.axis_i[0]) * (z.x - t.axis_i[0]);
-  T dq = (z.y - t.axis_q[0]) * (z.y - t.axis_q[0]);
-  for (int c = 1; c < L; ++c) {
-    T d = (z.x - t.axis_i[c]) * (z.x - t.axis_i[c]);
-    if (d < di) { di = d; bi = c; }
-    T e = (z.y - t.axis_q[c]) * (z.y - t.axis_q[c]);
-    if (e < dq) { dq = e; bq = c; }
+  switch (t.bits_per_axis) {
+    case 1: return demap_square<T, 1>(t, z);
+    case 2: return demap_square<T, 2>(t, z);
+    case 3: return demap_square<T, 3>(t, z);
+    default: return demap_square<T, 4>(t, z);
   }
-  return (bi << t.bits_per_axis) | bq;
 }
 
 // constellation point of a symbol index (for MER and mapping)

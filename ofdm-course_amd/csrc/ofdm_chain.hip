@@ -322,10 +322,27 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
 
 using namespace ofdm;
 
+namespace ofdm {
+struct FastPlanView {
+  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;
+  const void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram;
+  const std::vector<c64>* dict;
+  const ConstellationInfo* cinfo;
+  void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;
+  int64_t* ws_frames;
+};
+bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
+int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                   const void* ref, void* errs, void* h_out, void* idx_out);
+}  // namespace ofdm
+
 struct ofdm_rx_plan {
   int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
   int frame_words;
+  int pilots_in_band;
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
+  void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr;
+  int64_t ws_frames = 0;
   ConstellationInfo cinfo;
   std::vector<c64> dict;
 };
@@ -371,6 +388,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
   pl->nfft = nfft; pl->t_guard = t_guard; pl->n_symb = n_symb; pl->n_carrier = n_carrier; pl->np = n_pilots;
   pl->nd = n_data; pl->k_atoms = k_atoms; pl->taps = dominant_taps; pl->f64 = is_f64(flags) ? 1 : 0;
   pl->d_prole = pl->d_drole = pl->d_pilots = pl->d_sct = pl->d_gram = pl->d_pc0 = nullptr;
+  pl->pilots_in_band = 1;
   if (!constellation_info(constellation, pl->cinfo)) {
     delete pl;
     set_error("rx_plan_create: unknown constellation '%s'", constellation ? constellation : "(null)");
@@ -391,6 +409,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
     if (pilot_carriers[p] < 1 || pilot_carriers[p] > nfft) { set_error("rx_plan_create: pilot carrier outside 1..Nfft"); rc = OFDM_ERR_ARG; break; }
     pc0[p] = pilot_carriers[p] - 1;
     prole[pc0[p]] = (int16_t)p;
+    if (pilot_carriers[p] > n_carrier) pl->pilots_in_band = 0;
   }
   if (rc != OFDM_OK) { delete pl; return rc; }
   // conj(S) transposed: sct[p][k] = exp(+2 pi i pc0[p] k / nfft); Gram table g[d] = sum_p exp(-2 pi i pc0[p] d / nfft)
@@ -438,7 +457,8 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
 
 int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
-  void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0};
+  void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
+                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete pl;
   return OFDM_OK;
@@ -466,6 +486,19 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
   OFDM_TRY(st.out(index_out, sizeof(int32_t) * (size_t)pl->taps * n_frames, &didx));
   const void* tw = nullptr;
   OFDM_TRY(get_twiddles(pl->nfft, pl->f64 != 0, &tw));
+  if (pl->pilots_in_band &&
+      chain_fast_supported(pl->nfft, pl->n_carrier, pl->taps, pl->bps, (int64_t)pl->nd * pl->n_symb)) {
+    FastPlanView pv;
+    pv.nfft = pl->nfft; pv.t_guard = pl->t_guard; pv.n_symb = pl->n_symb; pv.n_carrier = pl->n_carrier;
+    pv.np = pl->np; pv.nd = pl->nd; pv.k_atoms = pl->k_atoms; pv.taps = pl->taps; pv.bps = pl->bps;
+    pv.f64 = pl->f64; pv.frame_words = pl->frame_words;
+    pv.d_prole = pl->d_prole; pv.d_drole = pl->d_drole; pv.d_pilots = pl->d_pilots; pv.d_sct = pl->d_sct;
+    pv.d_gram = pl->d_gram; pv.dict = &pl->dict; pv.cinfo = &pl->cinfo;
+    pv.ws_stash = &pl->ws_stash; pv.ws_ypil = &pl->ws_ypil; pv.ws_tapidx = &pl->ws_tapidx; pv.ws_tapx = &pl->ws_tapx;
+    pv.ws_frames = &pl->ws_frames;
+    OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
+    return st.finish();
+  }
 #define CALL(NN)                                                                                              \
   if (pl->f64) OFDM_TRY((launch_chain<double, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));      \
   else OFDM_TRY((launch_chain<float, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));

@@ -1,0 +1,679 @@
+// Fast path of the fused Task-5 RX chain for Nfft = 512 * NW (NW = 1, 2, 4, 8 wavefronts per frame),
+// i.e. the metric configuration Nfft = 2048 and its neighbours.  Three launches per batch:
+//
+//   rx_pilot_kernel    symbol 1 of every frame: FFT -> X1 stash (carriers 1..N_carrier) and
+//                      Y = X(pilotCarriers,1)./pilotValues(:,1)                     (Task5_part2.m:190)
+//   omp_batch_kernel   8 frames per workgroup: dictionary correlation c0 = S^H Y as ONE real GEMM on
+//                      the matrix cores (v_mfma_f32_16x16x4_f32, exact f32), then one wavefront per
+//                      frame runs the OMP iterations (OMP_estimate.m:7-23) in batch form
+//   rx_symbols_kernel  per frame: H = fft(h) on carriers 1..N_carrier from the taps, then every symbol:
+//                      FFT -> equalize_signal -> get_payload -> demapping -> packed bits -> BER numerator
+//
+// FFT structure (CDNA4-specific): one frame = NW wavefronts.  A radix-NW decimation-in-frequency
+// stage (registers + one LDS exchange, two workgroup barriers) splits the transform into NW
+// independent 512-point transforms, and each of those is done by ONE wavefront: 64 lanes x 8 points in
+// registers, three radix-8 passes whose two transposes go through a wave-private LDS region with no
+// workgroup barrier at all (a wavefront's LDS operations are processed in order).  Only the bins
+// k < N_carrier are ever needed, so the last pass computes 2 of its 8 outputs when N_carrier <= Nfft/4.
+// Global loads are 16 bytes per lane (NW = 4), twiddles live in registers for the whole launch.
+#include <cstdlib>
+#include <type_traits>
+
+#include "demap_core.hpp"
+#include "fft_core.hpp"
+
+namespace ofdm {
+
+constexpr int FAST_MAXT = 32;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__host__ __device__ constexpr int wpad(int i) { return i + (i >> 3); }
+constexpr int WAVE_LDS_ELEMS = 512 + 64;
+
+// Per-lane twiddle seeds.  Only w^1 is kept in registers (2 complex values per lane); the powers
+// w^2..w^7 are rebuilt per pass with six complex multiplies (depth 3) -- cheaper than 28 live VGPRs,
+// which cost a whole workgroup of occupancy per CU.
+template <typename T>
+struct WaveTw {
+  cx<T> b;   // W_64^(lane&7)
+  cx<T> c;   // W_512^lane
+};
+
+// tw = exp(-2 pi i m / N) table of the full transform, N = 512 * NW
+template <typename T, int NW>
+__device__ __forceinline__ void wave_tw_init(WaveTw<T>& w, int lane, const cx<T>* __restrict__ tw) {
+  w.b = tw[((lane & 7) * 8) * NW];
+  w.c = tw[lane * NW];
+}
+
+// v[t] *= w^t, t = 1..7
+template <typename T>
+__device__ __forceinline__ void twiddle_powers(cx<T> (&v)[8], cx<T> w1) {
+  const cx<T> w2 = w1 * w1, w4 = w2 * w2, w3 = w2 * w1;
+  v[1] = v[1] * w1;
+  v[2] = v[2] * w2;
+  v[3] = v[3] * w3;
+  v[4] = v[4] * w4;
+  v[5] = v[5] * (w4 * w1);
+  v[6] = v[6] * (w4 * w2);
+  v[7] = v[7] * (w4 * w3);
+}
+
+// X0 and X1 of an 8-point DFT (forward): v0 <- sum v_t ; v1 <- sum v_t W8^t
+template <typename T>
+__device__ __forceinline__ void dft8_first2(cx<T> (&v)[8]) {
+  const T h = T(0.70710678118654752440084436210485);
+  const cx<T> a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+  const cx<T> b0 = v[0] - v[4];
+  cx<T> b1 = v[1] - v[5], b2 = v[2] - v[6], b3 = v[3] - v[7];
+  b1 = mk<T>((b1.x + b1.y) * h, (b1.y - b1.x) * h);
+  b2 = mk<T>(b2.y, -b2.x);
+  b3 = mk<T>((b3.y - b3.x) * h, (-b3.x - b3.y) * h);
+  v[0] = (a0 + a2) + (a1 + a3);
+  v[1] = (b0 + b2) + (b1 + b3);
+}
+
+// Keeps a per-lane constant from being treated as loop invariant: without it the compiler hoists
+// the six twiddle-power multiplies of every pass out of the symbol loop and parks 28 VGPRs.
+template <typename T>
+__device__ __forceinline__ cx<T> opaque(cx<T> w) {
+  asm volatile("" : "+v"(w.x), "+v"(w.y));
+  return w;
+}
+
+// forward 512-point FFT inside one wavefront.  v[e] <-> y[lane + 64 e] on entry; on exit
+// v[t] = Y[lane + 64 t]  (t < 2 only when PRUNE2).  lw = this wavefront's private LDS region.
+// Padded addressing wpad(i) = i + i/8, written as one base per access pattern + immediates:
+//   scatter A : wpad(8 lane + t)            = 9 lane + t
+//   gather    : wpad(lane + 64 e)           = lane + lane/8 + 72 e
+//   scatter B : wpad(64 (lane/8) + lane%8 + 8 t) = 72 (lane/8) + lane%8 + 9 t
+template <typename T, bool PRUNE2>
+__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const WaveTw<T>& w, cx<T>* __restrict__ lw) {
+  cx<T>* const sa = lw + 9 * lane;
+  cx<T>* const ga = lw + lane + (lane >> 3);
+  cx<T>* const sb = lw + 72 * (lane >> 3) + (lane & 7);
+  dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) sa[t] = v[t];
+  wave_sync();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
+  wave_sync();
+  twiddle_powers<T>(v, opaque(w.b));
+  dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) sb[9 * t] = v[t];
+  wave_sync();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
+  wave_sync();
+  twiddle_powers<T>(v, opaque(w.c));
+  if constexpr (PRUNE2) dft8_first2<T>(v);
+  else dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+// ---- radix-NW decimation-in-frequency front end -------------------------------------------------
+// Thread gid (= 64*wave + lane) owns the butterflies m = gid*BPT + b, b < BPT = 8/NW.  Slot e = b*NW + t
+// holds x[m + 512 t].  After the stage slot b*NW + s holds y_s[m] = (sum_t x[m+512t] W_NW^(ts)) W_N^(m s).
+template <typename T, int NW>
+struct DifTw {
+  cx<T> w[NW > 1 ? (8 / NW) * (NW - 1) : 1];
+};
+
+template <typename T, int NW>
+__device__ __forceinline__ void dif_tw_init(DifTw<T, NW>& d, int gid, const cx<T>* __restrict__ tw) {
+  if constexpr (NW > 1) {
+    constexpr int BPT = 8 / NW;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b)
+#pragma unroll
+      for (int s = 1; s < NW; ++s) d.w[b * (NW - 1) + (s - 1)] = tw[(gid * BPT + b) * s];
+  }
+}
+
+template <typename T, int NW>
+__device__ __forceinline__ void frame_load(cx<T> (&v)[8], const cx<T>* __restrict__ src /* first useful sample */,
+                                           int gid, int lane) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[lane + 64 * e];
+  } else {
+    constexpr int BPT = 8 / NW;
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+      for (int b = 0; b < BPT; ++b) v[b * NW + t] = src[gid * BPT + b + 512 * t];
+  }
+}
+
+template <typename T, int NW>
+__device__ __forceinline__ void dif_stage(cx<T> (&v)[8], const DifTw<T, NW>& d) {
+  if constexpr (NW > 1) {
+    constexpr int BPT = 8 / NW;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+      if constexpr (NW == 2) dft2<T, false>(v[b * 2], v[b * 2 + 1]);
+      else if constexpr (NW == 4) dft4<T, false>(v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]);
+      else dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+      for (int s = 1; s < NW; ++s) v[b * NW + s] = v[b * NW + s] * d.w[b * (NW - 1) + (s - 1)];
+    }
+  }
+}
+
+// exchange: y_s[m] -> ex[s*576 + m]; then wavefront s gathers y_s[lane + 64 e].  Region s of the exchange
+// buffer doubles as wavefront s's private scratch for its 512-point transform: the barrier in front of
+// the next scatter is only reached by a wavefront that has finished its transform.
+template <typename T, int NW>
+__device__ __forceinline__ void dif_scatter(const cx<T> (&v)[8], int gid, cx<T>* __restrict__ ex) {
+  constexpr int BPT = 8 / NW;
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) ex[s * WAVE_LDS_ELEMS + gid * BPT + b] = v[b * NW + s];
+}
+template <typename T>
+__device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, const cx<T>* __restrict__ ex) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ex[wave * WAVE_LDS_ELEMS + lane + 64 * e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameters shared by the three kernels
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct FastParams {
+  int n_symb, t_guard, n_carrier, np, nd, k_atoms, taps, frame_words, bps;
+  const int16_t* prole;      // [nfft] pilot position of a carrier or -1
+  const int16_t* drole;      // [nfft] data position of a carrier or -1
+  const cx<T>* pilots;       // [np]
+  const cx<T>* sct;          // [np][k_atoms] conj(S), atom index fastest
+  const c64* gram;           // [k_atoms]
+  const cx<T>* tw;           // [nfft]
+  // workspace
+  cx<T>* stash;              // [n_frames][n_carrier]  X(1..N_carrier, 1)
+  cx<T>* ypil;               // [n_frames][np]
+  int32_t* tap_idx;          // [n_frames][taps]   0-based atom index, -1 = unused
+  c64* tap_x;                // [n_frames][taps]
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel 1: symbol 1 -> stash + Y
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NW, bool PRUNE2>
+__global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+                                                           int64_t n_frames) {
+  constexpr int N = 512 * NW;
+  constexpr int NOUT = PRUNE2 ? 2 : 8;
+  __shared__ cx<T> lwv[NW * WAVE_LDS_ELEMS];
+  cx<T>* const ex = lwv;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
+  WaveTw<T> wt;
+  DifTw<T, NW> dt;
+  wave_tw_init<T, NW>(wt, lane, P.tw);
+  dif_tw_init<T, NW>(dt, gid, P.tw);
+  int kk[NOUT], pp[NOUT];
+#pragma unroll
+  for (int t = 0; t < NOUT; ++t) {
+    kk[t] = NW * (lane + 64 * t) + wave;
+    pp[t] = kk[t] < P.n_carrier ? (int)P.prole[kk[t]] : -1;
+  }
+  const int64_t L = (int64_t)(N + P.t_guard) * P.n_symb;
+  cx<T> v[8];
+  for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    frame_load<T, NW>(v, rx + f * L + P.t_guard, gid, lane);
+    if constexpr (NW > 1) {
+      dif_stage<T, NW>(v, dt);
+      __syncthreads();
+      dif_scatter<T, NW>(v, gid, ex);
+      __syncthreads();
+      dif_gather<T>(v, wave, lane, ex);
+    }
+    wave_fft512<T, PRUNE2>(v, lane, wt, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) {
+      if (kk[t] < P.n_carrier) {
+        P.stash[f * P.n_carrier + kk[t]] = v[t];
+        if (pp[t] >= 0) P.ypil[f * P.np + pp[t]] = cdiv(v[t], P.pilots[pp[t]]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 2: batched OMP.  OMP_FB frames per workgroup of 4 wavefronts.
+// ---------------------------------------------------------------------------------------------
+constexpr int OMP_FB = 8;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct OmpLayout {          // byte offsets into dynamic LDS
+  unsigned off_y, off_c0, off_gram, off_wave, wave_bytes, total;
+};
+
+template <typename T>
+static OmpLayout omp_layout(int np, int k_atoms, int taps) {
+  OmpLayout o;
+  unsigned b = 0;
+  o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * OMP_FB * (np + 1) + 15) & ~15u);   // rows padded by one element
+  o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * OMP_FB * k_atoms + 15) & ~15u);
+  o.off_gram = b;  b += (unsigned)((sizeof(c64) * k_atoms + 15) & ~15u);
+  o.off_wave = b;
+  // per wavefront: L (taps*taps c64), z, x (taps c64 each), picks (taps int), ctl (4 ints)
+  o.wave_bytes = (unsigned)((sizeof(c64) * ((size_t)taps * taps + 2 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
+  b += 4 * o.wave_bytes;
+  o.total = b;
+  return o;
+}
+
+template <typename T, bool MFMA>
+__global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayout lay, int64_t n_frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* Yl = (cx<T>*)(smem + lay.off_y);       // [OMP_FB][np]
+  cx<T>* c0 = (cx<T>*)(smem + lay.off_c0);      // [OMP_FB][k_atoms]
+  c64* gl = (c64*)(smem + lay.off_gram);        // [k_atoms]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t f0 = (int64_t)blockIdx.x * OMP_FB;
+  const int np = P.np, K = P.k_atoms, taps = P.taps;
+  // ---- stage Y (zeros for frames past the end) and the Gram table
+  const int YS = np + 1;                        // LDS row stride of Y (bank-conflict padding)
+  for (int i = tid; i < OMP_FB * np; i += 256) {
+    const int f = i / np, p = i - f * np;
+    Yl[f * YS + p] = (f0 + f < n_frames) ? P.ypil[(f0 + f) * np + p] : mk<T>(0, 0);
+  }
+  for (int i = tid; i < K; i += 256) gl[i] = P.gram[i];
+  __syncthreads();
+  // ---- c0 = S^H Y for the OMP_FB frames
+  if constexpr (MFMA) {
+    // real GEMM  C[K x 16] = A[K x 2np] * B[2np x 16]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
+    // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
+    // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 (real parts of A, imaginary parts of A).
+    // A: lane (i = lane&15, q = lane>>4) supplies sct[p0+q][16*tile + i]; B: lane (n = lane&15, q) supplies
+    // column n at pilot p0+q.  C: lane holds rows 4*(lane>>4)+r of column lane&15.
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fcol = i16 >> 1, cim = i16 & 1;
+    const int n_tiles = K / 16;
+    for (int tile0 = wave * 2; tile0 < n_tiles; tile0 += 8) {
+      const bool two = tile0 + 1 < n_tiles;
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      for (int p0 = 0; p0 < np; p0 += 4) {
+        const cx<T> yv = Yl[fcol * YS + p0 + q];
+        const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
+        const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
+        const cx<T> a0 = P.sct[(size_t)(p0 + q) * K + tile0 * 16 + i16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc0, 0, 0, 0);
+        if (two) {
+          const cx<T> a1 = P.sct[(size_t)(p0 + q) * K + (tile0 + 1) * 16 + i16];
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc1, 0, 0, 0);
+        }
+      }
+      // C row = 4*q + r (atom within tile), column = i16 = (frame fcol, re/im cim)
+      float* c0f = (float*)c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c0f[2 * (fcol * K + tile0 * 16 + 4 * q + r) + cim] = acc0[r];
+        if (two) c0f[2 * (fcol * K + (tile0 + 1) * 16 + 4 * q + r) + cim] = acc1[r];
+      }
+    }
+  } else {
+    for (int i = tid; i < OMP_FB * K; i += 256) {
+      const int f = i / K, k = i - f * K;
+      cx<T> acc = mk<T>(0, 0);
+      for (int p = 0; p < np; ++p) acc = acc + P.sct[(size_t)p * K + k] * Yl[f * YS + p];
+      c0[i] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- one wavefront per frame: OMP iterations (wave-private state, no workgroup barrier below)
+  unsigned char* wb = smem + lay.off_wave + wave * lay.wave_bytes;
+  c64* Lm = (c64*)wb;                       // [taps][taps] lower Cholesky factor of the Gram
+  c64* zv = Lm + (size_t)taps * taps;       // L z = b
+  c64* xv = zv + taps;                      // L^H x = z
+  int* picks = (int*)(xv + taps);
+  int* ctl = picks + ((taps + 1) & ~1);     // [0] picks made, [1] stopped, [2..3] residual energy (double)
+  for (int fi = wave; fi < OMP_FB; fi += 4) {
+    const int64_t f = f0 + fi;
+    if (f >= n_frames) break;
+    const cx<T>* yf = Yl + fi * YS;
+    const cx<T>* cf = c0 + fi * K;
+    double ynorm = 0;
+    for (int p = lane; p < np; p += 64) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
+    double rho_prev = ynorm;
+    int n = 0;
+    bool stopped = false;
+    for (int it = 0; it < taps && !stopped; ++it) {
+      // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
+      float bs = -1.0f;
+      int bi = 0x7fffffff;
+      for (int k = lane; k < K; k += 64) {
+        cx<T> c = cf[k];
+        for (int qq = 0; qq < n; ++qq) {
+          const int d = picks[qq] - k;
+          const c64 gq = d >= 0 ? gl[d] : conj(gl[-d]);
+          const c64 t = gq * xv[qq];
+          c = c - mk<T>((T)t.x, (T)t.y);
+        }
+        const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
+        if (sc > bs) { bs = sc; bi = k; }          // ascending k inside a lane: strict > keeps the first
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl_xor(bs, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+      }
+      const int kp = bi < K ? bi : 0;                // all-NaN scores: MATLAB max returns index 1
+      if (lane == 0) {
+        int dup = -1;
+        for (int qq = 0; qq < n; ++qq) if (picks[qq] == kp) dup = qq;
+        if (dup >= 0) {
+          // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
+          const c64 half{xv[dup].x * 0.5, xv[dup].y * 0.5};
+          xv[dup] = half; xv[n] = half; picks[n] = kp;
+          ctl[0] = n + 1; ctl[1] = 1;
+        } else {
+          picks[n] = kp;
+          // new Cholesky row: G[n][j] = a_n^H a_j = gram[idx_j - idx_n]
+          double dd = gl[0].x;
+          for (int jq = 0; jq < n; ++jq) {
+            const int d = picks[jq] - kp;
+            c64 s = d >= 0 ? gl[d] : conj(gl[-d]);
+            for (int k2 = 0; k2 < jq; ++k2) s = s - mulc(Lm[n * taps + k2], Lm[jq * taps + k2]);
+            const double ljj = Lm[jq * taps + jq].x;
+            const c64 l = c64{s.x / ljj, s.y / ljj};
+            Lm[n * taps + jq] = l;
+            dd -= norm2(l);
+          }
+          const double lnn = sqrt(dd);
+          Lm[n * taps + n] = c64{lnn, 0};
+          // forward substitution (only the new entry changes): b_n = a_n^H y = c0[kp]
+          c64 s{(double)cf[kp].x, (double)cf[kp].y};
+          for (int k2 = 0; k2 < n; ++k2) s = s - Lm[n * taps + k2] * zv[k2];
+          zv[n] = c64{s.x / lnn, s.y / lnn};
+          // back substitution L^H x = z
+          for (int r = n; r >= 0; --r) {
+            c64 a = zv[r];
+            for (int k2 = r + 1; k2 <= n; ++k2) a = a - mulc(xv[k2], Lm[k2 * taps + r]);
+            const double l = Lm[r * taps + r].x;
+            xv[r] = c64{a.x / l, a.y / l};
+          }
+          // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
+          const double num = norm2(zv[n]);
+          int stop = 0;
+          if (it >= 1 && (!(num > 0.0) || sqrt(num / rho_prev) < 1e-2)) stop = 1;
+          ((double*)(ctl + 2))[0] = rho_prev - num;
+          ctl[0] = n + 1;
+          ctl[1] = stop;
+        }
+      }
+      wave_sync();
+      n = ctl[0];
+      stopped = ctl[1] != 0;
+      rho_prev = ((double*)(ctl + 2))[0];
+      wave_sync();
+    }
+    // est_fade_chan(index(i1)) = x(i1): a later duplicate overwrites an earlier one (:31-33)
+    if (lane < taps) {
+      int idx = -1;
+      c64 xo{0, 0};
+      if (lane < n) {
+        idx = picks[lane];
+        xo = xv[lane];
+        for (int q2 = lane + 1; q2 < n; ++q2) if (picks[q2] == idx) xo = c64{0, 0};
+      }
+      P.tap_idx[f * taps + lane] = idx;
+      P.tap_x[f * taps + lane] = xo;
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 3: all symbols of a frame
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NW, bool PRUNE2>
+__global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+                                                             int64_t n_frames, uint32_t* __restrict__ bits_out,
+                                                             const uint32_t* __restrict__ ref_bits,
+                                                             uint32_t* __restrict__ errors_out,
+                                                             cx<T>* __restrict__ h_out, int32_t* __restrict__ index_out,
+                                                             DemapTable<T> tab) {
+  constexpr int N = 512 * NW;
+  constexpr int NOUT = PRUNE2 ? 2 : 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* lwv = (cx<T>*)smem;                                           // [NW][WAVE_LDS_ELEMS]
+  cx<T>* const ex = lwv;                                               // exchange regions alias the private ones
+  uint8_t* codes = (uint8_t*)(lwv + NW * WAVE_LDS_ELEMS);              // [n_symb * nd]
+  __shared__ unsigned int sh_err;
+  __shared__ int sh_tidx[FAST_MAXT];
+  __shared__ c64 sh_tx[FAST_MAXT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
+  WaveTw<T> wt;
+  DifTw<T, NW> dt;
+  wave_tw_init<T, NW>(wt, lane, P.tw);
+  dif_tw_init<T, NW>(dt, gid, P.tw);
+  int kk[NOUT], dd[NOUT];
+#pragma unroll
+  for (int t = 0; t < NOUT; ++t) {
+    kk[t] = NW * (lane + 64 * t) + wave;
+    dd[t] = kk[t] < P.n_carrier ? (int)P.drole[kk[t]] : -1;
+  }
+  const int Lsym = N + P.t_guard;
+  const int taps = P.taps, bps = P.bps, nd = P.nd;
+  const int64_t frame_bits = (int64_t)nd * P.n_symb * bps;
+  const int n_codes = nd * P.n_symb;
+  if (gid < 32) codes[((n_codes + 31) & ~31) - 32 + gid] = 0;      // zero padding of the last 32-symbol group
+  __syncthreads();
+  cx<T> v[8], nx[8];
+  for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    const cx<T>* frx = rx + f * (int64_t)Lsym * P.n_symb;
+    if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane);
+    if (gid == 0) sh_err = 0;
+    // ---- H = fft(h)(1..N_carrier) from the taps; G = 1 ./ H           (OMP_estimate.m:36, equalize_signal.m:6)
+    if (gid < taps) {
+      const int idx = P.tap_idx[f * taps + gid];
+      sh_tidx[gid] = idx;
+      sh_tx[gid] = P.tap_x[f * taps + gid];
+      if (index_out) index_out[f * taps + gid] = idx + 1;
+    }
+    __syncthreads();
+    cx<T> geq[NOUT];
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) {
+      geq[t] = mk<T>(0, 0);
+      if (kk[t] < P.n_carrier) {
+        double hr = 0, hi = 0;
+        for (int q = 0; q < taps; ++q) {
+          const int idx = sh_tidx[q];
+          const c64 x = sh_tx[q];                       // zero for unused / overwritten slots
+          const cx<T> w = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * kk[t]) & (N - 1))];
+          hr += x.x * (double)w.x - x.y * (double)w.y;
+          hi += x.x * (double)w.y + x.y * (double)w.x;
+        }
+        const cx<T> H = mk<T>((T)hr, (T)hi);
+        if (h_out) h_out[f * P.n_carrier + kk[t]] = H;
+        geq[t] = cdiv(mk<T>(1, 0), H);
+      }
+    }
+    // ---- symbol 1 from the stash
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t)
+      if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
+    // ---- symbols 2..S
+    for (int s = 1; s < P.n_symb; ++s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = nx[e];
+      if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
+      if constexpr (NW > 1) {
+        dif_stage<T, NW>(v, dt);
+        __syncthreads();                 // every wavefront has finished gathering the previous symbol
+        dif_scatter<T, NW>(v, gid, ex);
+        __syncthreads();
+        dif_gather<T>(v, wave, lane, ex);
+      }
+      wave_fft512<T, PRUNE2>(v, lane, wt, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t)
+        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
+    }
+    __syncthreads();
+    // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
+    //      symbols is exactly `bps` 32-bit words: two 16-byte LDS reads, then registers only.
+    unsigned int err = 0;
+    const int n_groups = (n_codes + 31) >> 5;
+    for (int grp = gid; grp < n_groups; grp += 64 * NW) {
+      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
+      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
+      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+      unsigned long long acc = 0;
+      int nb = 0, w = grp * bps;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const uint32_t code = (cw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+        acc = (acc << bps) | code;
+        nb += bps;
+        if (nb >= 32) {
+          nb -= 32;
+          const uint32_t word = __builtin_bswap32((uint32_t)(acc >> nb));
+          if (w < P.frame_words) {
+            if (bits_out) bits_out[f * P.frame_words + w] = word;
+            if (ref_bits) err += __popc(word ^ ref_bits[f * P.frame_words + w]);
+          }
+          ++w;
+        }
+      }
+    }
+    (void)frame_bits;
+    if (ref_bits && errors_out) {
+      if (err) atomicAdd(&sh_err, err);
+      __syncthreads();
+      if (gid == 0) errors_out[f] = sh_err;
+    }
+    __syncthreads();                     // codes / sh_err are reused by the next frame
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct FastPlanView {
+  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;
+  const void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram;
+  const std::vector<c64>* dict;
+  const ConstellationInfo* cinfo;
+  void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;   // workspace owned by the plan
+  int64_t* ws_frames;
+};
+
+bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
+  if (getenv("OFDM_CHAIN_GENERIC")) return false;
+  if (!(nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096)) return false;
+  if (taps > FAST_MAXT || bps > 8) return false;
+  if (nd_nsymb > 48 * 1024) return false;
+  (void)n_carrier;
+  return true;
+}
+
+template <typename T, int NW, bool PRUNE2>
+static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                       const void* ref, void* errs, void* h_out, void* idx_out) {
+  FastParams<T> P;
+  P.n_symb = pv.n_symb; P.t_guard = pv.t_guard; P.n_carrier = pv.n_carrier; P.np = pv.np; P.nd = pv.nd;
+  P.k_atoms = pv.k_atoms; P.taps = pv.taps; P.frame_words = pv.frame_words; P.bps = pv.bps;
+  P.prole = (const int16_t*)pv.d_prole; P.drole = (const int16_t*)pv.d_drole;
+  P.pilots = (const cx<T>*)pv.d_pilots; P.sct = (const cx<T>*)pv.d_sct; P.gram = (const c64*)pv.d_gram;
+  P.tw = (const cx<T>*)tw;
+  // workspace (grown on demand, kept by the plan)
+  if (*pv.ws_frames < n_frames) {
+    void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx};
+    OFDM_HIP(hipStreamSynchronize(ctx().stream));
+    for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    OFDM_HIP(hipMalloc(pv.ws_stash, sizeof(cx<T>) * (size_t)pv.n_carrier * n_frames));
+    OFDM_HIP(hipMalloc(pv.ws_ypil, sizeof(cx<T>) * (size_t)pv.np * n_frames));
+    OFDM_HIP(hipMalloc(pv.ws_tapidx, sizeof(int32_t) * (size_t)pv.taps * n_frames));
+    OFDM_HIP(hipMalloc(pv.ws_tapx, sizeof(c64) * (size_t)pv.taps * n_frames));
+    *pv.ws_frames = n_frames;
+  }
+  P.stash = (cx<T>*)*pv.ws_stash; P.ypil = (cx<T>*)*pv.ws_ypil;
+  P.tap_idx = (int32_t*)*pv.ws_tapidx; P.tap_x = (c64*)*pv.ws_tapx;
+  DemapTable<T> tab;
+  fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
+  const int ncu = ctx().num_cu;
+  hipStream_t st = ctx().stream;
+  // kernel 1
+  {
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * 8);
+    hipLaunchKernelGGL((rx_pilot_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), 0, st, P, (const cx<T>*)rx, n_frames);
+    OFDM_TRY(check_launch("rx_pilot_kernel"));
+  }
+  // kernel 2
+  {
+    const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
+    OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
+    const unsigned grid = cdiv_u(n_frames, OMP_FB);
+    const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) &&
+                      !getenv("OFDM_OMP_NO_MFMA");
+    if (mfma) {
+      if constexpr (std::is_same<T, float>::value) {
+        OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+        hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+      }
+    } else {
+      OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+      hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+    }
+    OFDM_TRY(check_launch("omp_batch_kernel"));
+  }
+  // kernel 3
+  {
+    constexpr int N = 512 * NW;
+    const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS) +
+                       (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+    OFDM_ARG(dyn <= 150 * 1024, "rx_chain_task5: symbol stage needs %zu bytes of LDS", dyn);
+    // occupancy: 128 VGPRs -> 4 waves per SIMD; a workgroup puts NW/4 waves on every SIMD
+    const int by_vgpr = std::max(1, 16 / NW);
+    const int per_cu = std::max(1, std::min(by_vgpr, (int)(156 * 1024 / (dyn + 1024))));
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
+    OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
+                       n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
+                       (int32_t*)idx_out, tab);
+    OFDM_TRY(check_launch("rx_symbols_kernel"));
+  }
+  return OFDM_OK;
+}
+
+template <typename T>
+static int dispatch_fast(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                         const void* ref, void* errs, void* h_out, void* idx_out) {
+  const int nw = pv.nfft / 512;
+  const bool prune = pv.n_carrier <= 128 * nw;
+#define FAST_CALL(NWV)                                                                                       \
+  return prune ? launch_fast<T, NWV, true>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out)            \
+               : launch_fast<T, NWV, false>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out)
+  switch (nw) {
+    case 1: FAST_CALL(1);
+    case 2: FAST_CALL(2);
+    case 4: FAST_CALL(4);
+    case 8: FAST_CALL(8);
+  }
+#undef FAST_CALL
+  set_error("rx_chain_task5(fast): unsupported Nfft %d", pv.nfft);
+  return OFDM_ERR_UNSUPPORTED;
+}
+
+int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                   const void* ref, void* errs, void* h_out, void* idx_out) {
+  if (pv.f64) return dispatch_fast<double>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out);
+  return dispatch_fast<float>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out);
+}
+
+}  // namespace ofdm

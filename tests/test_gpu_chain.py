@@ -20,11 +20,19 @@ def _run(ofdm, oracle, cfg, n_frames, precision, seed=1):
     return data, out, ref, got_bits
 
 
+@pytest.mark.parametrize("path", ["fast", "generic"])
 @pytest.mark.parametrize("precision", ["fp64", "fp32"])
-@pytest.mark.parametrize("nfft,nc,const", [(64, 32, "QPSK"), (256, 64, "16QAM"), (1024, 256, "64QAM"),
-                                            (2048, 512, "64QAM")])
-def test_chain_matches_oracle(ofdm, oracle, precision, nfft, nc, const):
+@pytest.mark.parametrize("nfft,nc,const", [(64, 32, "QPSK"), (256, 64, "16QAM"), (512, 100, "8PSK"),
+                                            (1024, 256, "64QAM"), (1024, 400, "16QAM"), (2048, 512, "64QAM"),
+                                            (4096, 1024, "256QAM")])
+def test_chain_matches_oracle(ofdm, oracle, monkeypatch, path, precision, nfft, nc, const):
+    """`fast` = 3-kernel pipeline (wave-local FFT + MFMA correlation) where supported (Nfft 512..4096),
+    `generic` = single fused kernel (every Nfft).  Both must reproduce the oracle."""
     from ofdm_course_amd import frames as fr
+    if path == "generic":
+        monkeypatch.setenv("OFDM_CHAIN_GENERIC", "1")
+    else:
+        monkeypatch.delenv("OFDM_CHAIN_GENERIC", raising=False)
     cfg = fr.config_small(nfft=nfft, n_carrier=nc, comb=4, const=const, n_symb=4 if nfft < 2048 else 14,
                           dominant_taps=3)
     if nfft == 2048:
