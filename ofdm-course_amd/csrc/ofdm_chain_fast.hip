@@ -35,33 +35,20 @@ __device__ __forceinline__ void wave_sync() {
 __host__ __device__ constexpr int wpad(int i) { return i + (i >> 3); }
 constexpr int WAVE_LDS_ELEMS = 512 + 64;
 
-// Per-lane twiddle seeds.  Only w^1 is kept in registers (2 complex values per lane); the powers
-// w^2..w^7 are rebuilt per pass with six complex multiplies (depth 3) -- cheaper than 28 live VGPRs,
-// which cost a whole workgroup of occupancy per CU.
-template <typename T>
-struct WaveTw {
-  cx<T> b;   // W_64^(lane&7)
-  cx<T> c;   // W_512^lane
-};
+// Twiddles of the two inner passes of the wave-local 512-point transform, kept in LDS as
+// [pass][t-1][lane] (lane-contiguous: conflict-free ds_read_b64, no VALU, no live registers):
+//   pass B: W_64^(t*(lane&7))      pass C: W_512^(t*lane)        t = 1..7
+// 2 * 7 * 64 complex values, shared by every wavefront of the workgroup.
+constexpr int WAVE_TW_ELEMS = 2 * 7 * 64;
 
-// tw = exp(-2 pi i m / N) table of the full transform, N = 512 * NW
+// tw = exp(-2 pi i m / N) table of the full transform, N = 512 * NW.  Call with all threads; the
+// caller synchronises the workgroup before the first transform.
 template <typename T, int NW>
-__device__ __forceinline__ void wave_tw_init(WaveTw<T>& w, int lane, const cx<T>* __restrict__ tw) {
-  w.b = tw[((lane & 7) * 8) * NW];
-  w.c = tw[lane * NW];
-}
-
-// v[t] *= w^t, t = 1..7
-template <typename T>
-__device__ __forceinline__ void twiddle_powers(cx<T> (&v)[8], cx<T> w1) {
-  const cx<T> w2 = w1 * w1, w4 = w2 * w2, w3 = w2 * w1;
-  v[1] = v[1] * w1;
-  v[2] = v[2] * w2;
-  v[3] = v[3] * w3;
-  v[4] = v[4] * w4;
-  v[5] = v[5] * (w4 * w1);
-  v[6] = v[6] * (w4 * w2);
-  v[7] = v[7] * (w4 * w3);
+__device__ __forceinline__ void wave_tw_fill(cx<T>* __restrict__ twl, const cx<T>* __restrict__ tw) {
+  for (int i = threadIdx.x; i < WAVE_TW_ELEMS; i += 64 * NW) {
+    const int pass = i / 448, r = i - pass * 448, t = r / 64 + 1, l = r & 63;
+    twl[i] = pass == 0 ? tw[(t * (l & 7) * 8) * NW] : tw[(t * l) * NW];
+  }
 }
 
 // X0 and X1 of an 8-point DFT (forward): v0 <- sum v_t ; v1 <- sum v_t W8^t
@@ -78,14 +65,6 @@ __device__ __forceinline__ void dft8_first2(cx<T> (&v)[8]) {
   v[1] = (b0 + b2) + (b1 + b3);
 }
 
-// Keeps a per-lane constant from being treated as loop invariant: without it the compiler hoists
-// the six twiddle-power multiplies of every pass out of the symbol loop and parks 28 VGPRs.
-template <typename T>
-__device__ __forceinline__ cx<T> opaque(cx<T> w) {
-  asm volatile("" : "+v"(w.x), "+v"(w.y));
-  return w;
-}
-
 // forward 512-point FFT inside one wavefront.  v[e] <-> y[lane + 64 e] on entry; on exit
 // v[t] = Y[lane + 64 t]  (t < 2 only when PRUNE2).  lw = this wavefront's private LDS region.
 // Padded addressing wpad(i) = i + i/8, written as one base per access pattern + immediates:
@@ -93,7 +72,8 @@ __device__ __forceinline__ cx<T> opaque(cx<T> w) {
 //   gather    : wpad(lane + 64 e)           = lane + lane/8 + 72 e
 //   scatter B : wpad(64 (lane/8) + lane%8 + 8 t) = 72 (lane/8) + lane%8 + 9 t
 template <typename T, bool PRUNE2>
-__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const WaveTw<T>& w, cx<T>* __restrict__ lw) {
+__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T>* __restrict__ twl,
+                                            cx<T>* __restrict__ lw) {
   cx<T>* const sa = lw + 9 * lane;
   cx<T>* const ga = lw + lane + (lane >> 3);
   cx<T>* const sb = lw + 72 * (lane >> 3) + (lane & 7);
@@ -104,7 +84,8 @@ __device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const WaveT
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
   wave_sync();
-  twiddle_powers<T>(v, opaque(w.b));
+#pragma unroll
+  for (int t = 1; t < 8; ++t) v[t] = v[t] * twl[(t - 1) * 64 + lane];
   dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
   for (int t = 0; t < 8; ++t) sb[9 * t] = v[t];
@@ -112,7 +93,8 @@ __device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const WaveT
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
   wave_sync();
-  twiddle_powers<T>(v, opaque(w.c));
+#pragma unroll
+  for (int t = 1; t < 8; ++t) v[t] = v[t] * twl[448 + (t - 1) * 64 + lane];
   if constexpr (PRUNE2) dft8_first2<T>(v);
   else dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
@@ -211,12 +193,13 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
   constexpr int N = 512 * NW;
   constexpr int NOUT = PRUNE2 ? 2 : 8;
   __shared__ cx<T> lwv[NW * WAVE_LDS_ELEMS];
+  __shared__ cx<T> twl[WAVE_TW_ELEMS];
   cx<T>* const ex = lwv;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
-  WaveTw<T> wt;
   DifTw<T, NW> dt;
-  wave_tw_init<T, NW>(wt, lane, P.tw);
+  wave_tw_fill<T, NW>(twl, P.tw);
   dif_tw_init<T, NW>(dt, gid, P.tw);
+  __syncthreads();
   int kk[NOUT], pp[NOUT];
 #pragma unroll
   for (int t = 0; t < NOUT; ++t) {
@@ -234,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
       __syncthreads();
       dif_gather<T>(v, wave, lane, ex);
     }
-    wave_fft512<T, PRUNE2>(v, lane, wt, lwv + wave * WAVE_LDS_ELEMS);
+    wave_fft512<T, PRUNE2>(v, lane, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) {
       if (kk[t] < P.n_carrier) {
@@ -451,14 +434,14 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* lwv = (cx<T>*)smem;                                           // [NW][WAVE_LDS_ELEMS]
   cx<T>* const ex = lwv;                                               // exchange regions alias the private ones
-  uint8_t* codes = (uint8_t*)(lwv + NW * WAVE_LDS_ELEMS);              // [n_symb * nd]
+  cx<T>* twl = lwv + NW * WAVE_LDS_ELEMS;                              // [WAVE_TW_ELEMS]
+  uint8_t* codes = (uint8_t*)(twl + WAVE_TW_ELEMS);                    // [n_symb * nd]
   __shared__ unsigned int sh_err;
   __shared__ int sh_tidx[FAST_MAXT];
   __shared__ c64 sh_tx[FAST_MAXT];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
-  WaveTw<T> wt;
   DifTw<T, NW> dt;
-  wave_tw_init<T, NW>(wt, lane, P.tw);
+  wave_tw_fill<T, NW>(twl, P.tw);
   dif_tw_init<T, NW>(dt, gid, P.tw);
   int kk[NOUT], dd[NOUT];
 #pragma unroll
@@ -519,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
         __syncthreads();
         dif_gather<T>(v, wave, lane, ex);
       }
-      wave_fft512<T, PRUNE2>(v, lane, wt, lwv + wave * WAVE_LDS_ELEMS);
+      wave_fft512<T, PRUNE2>(v, lane, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
       for (int t = 0; t < NOUT; ++t)
         if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
@@ -635,7 +618,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   // kernel 3
   {
     constexpr int N = 512 * NW;
-    const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS) +
+    const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS) +
                        (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
     OFDM_ARG(dyn <= 150 * 1024, "rx_chain_task5: symbol stage needs %zu bytes of LDS", dyn);
     // occupancy: 128 VGPRs -> 4 waves per SIMD; a workgroup puts NW/4 waves on every SIMD
