@@ -94,3 +94,15 @@ def test_sweep_sharding_is_a_partition():
     assert sweep.tile_seed_stream(7, 3, 5, 64) == sweep.tile_seed_stream(7, 3, 5, 64)
     with pytest.raises(ValueError):
         sweep.tiles_for_rank(20, 13, 8, 8)
+
+
+def test_mex_gateways_typecheck_against_the_header():
+    """Every MEX gateway compiles (syntax/type level) against include/ofdm_mi355x.h."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "check_mex_syntax.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "ofdm-course_amd", "mex")) if f.endswith(".cpp"))
+    assert len(names) == 25 and "OMP_estimate" in names and "AutoCorrFunction" in names
