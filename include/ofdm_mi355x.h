@@ -185,6 +185,11 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
  * h_out (may be NULL): [n_carrier x n_frames] OMP estimate; index_out (may be NULL): [dominant_taps x n_frames]
  * 1-based picks, 0 = unused slot. */
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
+/* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
+ * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call
+ * (the generic single-kernel path reports {0, 0, total}). */
+int ofdm_rx_plan_set_timing(ofdm_rx_plan* plan, int enable);
+int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* plan, float* ms3);
 int ofdm_rx_chain_task5(ofdm_rx_plan* plan, const void* rx, int64_t n_frames,
                         uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out,
                         void* h_out, int32_t* index_out, int flags);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "ofdm_rx_plan_create": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _cp, _i],
     "ofdm_rx_plan_destroy": [_vp],
     "ofdm_rx_plan_frame_bytes": [_vp],
+    "ofdm_rx_plan_set_timing": [_vp, _i],
+    "ofdm_rx_plan_last_kernel_ms": [_vp, C.POINTER(C.c_float)],
     "ofdm_rx_chain_task5": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i],
 }
 _RESTYPES = {"ofdm_last_error_string": C.c_char_p, "ofdm_rx_plan_frame_bytes": C.c_int64}

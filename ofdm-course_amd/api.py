@@ -606,6 +606,15 @@ class RxPlan:
         self.frame_bits = self.n_data * self.N_symb * self.bps
         self.frame_samples = (self.Nfft + self.T_guard) * self.N_symb
 
+    def set_timing(self, enable=True):
+        L.check(self.lib.ofdm_rx_plan_set_timing(self.handle, int(bool(enable))), "rx_plan_set_timing")
+
+    def last_kernel_ms(self):
+        """(symbol-1 kernel, OMP kernel, symbols kernel) milliseconds of the last chain call (HIP events)."""
+        ms = (C.c_float * 3)()
+        L.check(self.lib.ofdm_rx_plan_last_kernel_ms(self.handle, ms), "rx_plan_last_kernel_ms")
+        return tuple(float(v) for v in ms)
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.ofdm_rx_plan_destroy(self.handle)

@@ -330,6 +330,7 @@ struct FastPlanView {
   const ConstellationInfo* cinfo;
   void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;
   int64_t* ws_frames;
+  hipEvent_t* ev;
 };
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
 int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
@@ -343,6 +344,9 @@ struct ofdm_rx_plan {
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
   void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr;
   int64_t ws_frames = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int timing = 0;          // ofdm_rx_plan_set_timing
+  int last_fast = 0;
   ConstellationInfo cinfo;
   std::vector<c64> dict;
 };
@@ -460,7 +464,28 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
                   pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   delete pl;
+  return OFDM_OK;
+}
+
+int ofdm_rx_plan_set_timing(ofdm_rx_plan* pl, int enable) {
+  OFDM_ARG(pl, "rx_plan_set_timing: null plan");
+  if (enable && !pl->ev[0])
+    for (int i = 0; i < 4; ++i) OFDM_HIP(hipEventCreate(&pl->ev[i]));
+  pl->timing = enable ? 1 : 0;
+  return OFDM_OK;
+}
+
+int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* pl, float* ms3) {
+  OFDM_ARG(pl && ms3 && pl->timing && pl->ev[0], "rx_plan_last_kernel_ms: timing is not enabled");
+  OFDM_HIP(hipEventSynchronize(pl->ev[3]));
+  if (pl->last_fast) {
+    for (int i = 0; i < 3; ++i) OFDM_HIP(hipEventElapsedTime(&ms3[i], pl->ev[i], pl->ev[i + 1]));
+  } else {
+    ms3[0] = ms3[1] = 0.f;
+    OFDM_HIP(hipEventElapsedTime(&ms3[2], pl->ev[0], pl->ev[3]));
+  }
   return OFDM_OK;
 }
 
@@ -496,14 +521,19 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.d_gram = pl->d_gram; pv.dict = &pl->dict; pv.cinfo = &pl->cinfo;
     pv.ws_stash = &pl->ws_stash; pv.ws_ypil = &pl->ws_ypil; pv.ws_tapidx = &pl->ws_tapidx; pv.ws_tapx = &pl->ws_tapx;
     pv.ws_frames = &pl->ws_frames;
+    pv.ev = pl->timing ? pl->ev : nullptr;
+    pl->last_fast = 1;
     OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
     return st.finish();
   }
+  pl->last_fast = 0;
+  if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[0], ctx().stream));
 #define CALL(NN)                                                                                              \
   if (pl->f64) OFDM_TRY((launch_chain<double, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));      \
   else OFDM_TRY((launch_chain<float, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));
   OFDM_FFT_DISPATCH(pl->nfft, CALL)
 #undef CALL
+  if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[3], ctx().stream));
   return st.finish();
 }
 

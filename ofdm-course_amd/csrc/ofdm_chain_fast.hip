@@ -554,6 +554,7 @@ struct FastPlanView {
   const ConstellationInfo* cinfo;
   void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;   // workspace owned by the plan
   int64_t* ws_frames;
+  hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
 };
 
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
@@ -591,12 +592,14 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
   const int ncu = ctx().num_cu;
   hipStream_t st = ctx().stream;
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
   // kernel 1
   {
     const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * 8);
     hipLaunchKernelGGL((rx_pilot_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), 0, st, P, (const cx<T>*)rx, n_frames);
     OFDM_TRY(check_launch("rx_pilot_kernel"));
   }
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
   // kernel 2
   {
     const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
@@ -615,6 +618,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     }
     OFDM_TRY(check_launch("omp_batch_kernel"));
   }
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
   // kernel 3
   {
     constexpr int N = 512 * NW;
@@ -631,6 +635,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
                        (int32_t*)idx_out, tab);
     OFDM_TRY(check_launch("rx_symbols_kernel"));
   }
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
   return OFDM_OK;
 }
 
