@@ -171,6 +171,7 @@ __device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, co
 template <typename T>
 struct FastParams {
   int n_symb, t_guard, n_carrier, np, nd, k_atoms, taps, frame_words, bps;
+  int dbg;                   // diagnostics only (env OFDM_FAST_SKIP)
   const int16_t* prole;      // [nfft] pilot position of a carrier or -1
   const int16_t* drole;      // [nfft] data position of a carrier or -1
   const cx<T>* pilots;       // [np]
@@ -229,26 +230,37 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 2: batched OMP.  OMP_FB frames per workgroup of 4 wavefronts.
+// kernel 2: batched OMP.  A workgroup of 4 wavefronts owns FB = 4 * FPW frames (FPW = 8, 4, 2 or 1
+// frames per wavefront, chosen on the host from the LDS the per-frame state needs).
+//   stage 1: c0 = S^H Y for all FB frames as one real GEMM on the matrix cores
+//   stage 2: each wavefront runs the OMP iterations of FPW frames SIDE BY SIDE: a frame is a group
+//            of LPF = 64/FPW lanes (arg-max by xor-shuffles inside the group); the short serial part
+//            (Cholesky row, two triangular solves) runs on the first lane of every group, i.e. for FPW
+//            frames at once.  Solve arithmetic is in the data precision T (double in parity mode).
 // ---------------------------------------------------------------------------------------------
-constexpr int OMP_FB = 8;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct OmpLayout {          // byte offsets into dynamic LDS
-  unsigned off_y, off_c0, off_gram, off_wave, wave_bytes, total;
+  unsigned off_y, off_c0, off_gram, off_state, state_bytes, total;
+  int fpw;                  // frames per wavefront
 };
 
 template <typename T>
 static OmpLayout omp_layout(int np, int k_atoms, int taps) {
   OmpLayout o;
+  // per frame: L (taps*taps), z, x (taps each) complex T; picks (taps ints); ctl (n, stop) + rho (double)
+  o.state_bytes = (unsigned)((sizeof(cx<T>) * ((size_t)taps * taps + 2 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
+  const size_t per_frame = sizeof(cx<T>) * (np + 1) + sizeof(cx<T>) * k_atoms + o.state_bytes;
+  int fpw = 4;                // 16 frames per workgroup: 2 workgroups per CU keep 8 wavefronts in flight
+  if (const char* e = getenv("OFDM_OMP_FPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) fpw = v; }
+  while (fpw > 1 && 4 * fpw * per_frame + sizeof(cx<T>) * k_atoms > 96 * 1024) fpw >>= 1;
+  o.fpw = fpw;
+  const int fb = 4 * fpw;
   unsigned b = 0;
-  o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * OMP_FB * (np + 1) + 15) & ~15u);   // rows padded by one element
-  o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * OMP_FB * k_atoms + 15) & ~15u);
-  o.off_gram = b;  b += (unsigned)((sizeof(c64) * k_atoms + 15) & ~15u);
-  o.off_wave = b;
-  // per wavefront: L (taps*taps c64), z, x (taps c64 each), picks (taps int), ctl (4 ints)
-  o.wave_bytes = (unsigned)((sizeof(c64) * ((size_t)taps * taps + 2 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
-  b += 4 * o.wave_bytes;
+  o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * fb * (np + 1) + 15) & ~15u);   // rows padded by one element
+  o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * fb * k_atoms + 15) & ~15u);
+  o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * k_atoms + 15) & ~15u);
+  o.off_state = b; b += fb * o.state_bytes;
   o.total = b;
   return o;
 }
@@ -256,56 +268,77 @@ static OmpLayout omp_layout(int np, int k_atoms, int taps) {
 template <typename T, bool MFMA>
 __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayout lay, int64_t n_frames) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cx<T>* Yl = (cx<T>*)(smem + lay.off_y);       // [OMP_FB][np]
-  cx<T>* c0 = (cx<T>*)(smem + lay.off_c0);      // [OMP_FB][k_atoms]
-  c64* gl = (c64*)(smem + lay.off_gram);        // [k_atoms]
+  cx<T>* Yl = (cx<T>*)(smem + lay.off_y);       // [FB][np + 1]
+  cx<T>* c0 = (cx<T>*)(smem + lay.off_c0);      // [FB][k_atoms]
+  cx<T>* gl = (cx<T>*)(smem + lay.off_gram);    // [k_atoms] Gram table in the working precision
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t f0 = (int64_t)blockIdx.x * OMP_FB;
+  const int FPW = lay.fpw, FB = 4 * FPW;
+  const int64_t f0 = (int64_t)blockIdx.x * FB;
   const int np = P.np, K = P.k_atoms, taps = P.taps;
-  // ---- stage Y (zeros for frames past the end) and the Gram table
   const int YS = np + 1;                        // LDS row stride of Y (bank-conflict padding)
-  for (int i = tid; i < OMP_FB * np; i += 256) {
+  // ---- stage Y (zeros for frames past the end) and the Gram table
+  for (int i = tid; i < FB * np; i += 256) {
     const int f = i / np, p = i - f * np;
     Yl[f * YS + p] = (f0 + f < n_frames) ? P.ypil[(f0 + f) * np + p] : mk<T>(0, 0);
   }
-  for (int i = tid; i < K; i += 256) gl[i] = P.gram[i];
+  for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
   __syncthreads();
-  // ---- c0 = S^H Y for the OMP_FB frames
-  if constexpr (MFMA) {
-    // real GEMM  C[K x 16] = A[K x 2np] * B[2np x 16]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
+  // ---- c0 = S^H Y
+  if (P.dbg & 1) {
+    for (int i = tid; i < FB * K; i += 256) c0[i] = mk<T>((T)(i & 7), (T)1);
+  } else if constexpr (MFMA) {
+    // real GEMM  C[K x 2 FB] = A[K x 2np] * B[2np x 2 FB]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
     // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
-    // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 (real parts of A, imaginary parts of A).
-    // A: lane (i = lane&15, q = lane>>4) supplies sct[p0+q][16*tile + i]; B: lane (n = lane&15, q) supplies
-    // column n at pilot p0+q.  C: lane holds rows 4*(lane>>4)+r of column lane&15.
+    // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 per 16x16 tile (real / imaginary parts of A).
+    // A: lane (i = lane&15, q = lane>>4) supplies sct[p0+q][16*tile + i], loaded once per k-step and reused
+    // for every 16-column group; B: lane (n = lane&15, q) supplies column n at pilot p0+q (LDS).
+    // C: lane holds rows 4*(lane>>4)+r of column lane&15.
     const int i16 = lane & 15, q = lane >> 4;
-    const int fcol = i16 >> 1, cim = i16 & 1;
+    const int fsub = i16 >> 1, cim = i16 & 1;
     const int n_tiles = K / 16;
+    const int n_cg = FB / 8;                       // 16-column groups (8 frames each): 1, 2 or 4
     for (int tile0 = wave * 2; tile0 < n_tiles; tile0 += 8) {
       const bool two = tile0 + 1 < n_tiles;
-      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
+      const cx<T>* a0p = P.sct + tile0 * 16 + i16;
+      cx<T> a0 = a0p[(size_t)q * K], a1 = two ? a0p[(size_t)q * K + 16] : mk<T>(0, 0);
       for (int p0 = 0; p0 < np; p0 += 4) {
-        const cx<T> yv = Yl[fcol * YS + p0 + q];
-        const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
-        const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
-        const cx<T> a0 = P.sct[(size_t)(p0 + q) * K + tile0 * 16 + i16];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc0, 0, 0, 0);
-        if (two) {
-          const cx<T> a1 = P.sct[(size_t)(p0 + q) * K + (tile0 + 1) * 16 + i16];
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc1, 0, 0, 0);
+        // prefetch the next k-step's A operands while this step's MFMAs issue
+        const int pn = p0 + 4 < np ? p0 + 4 : p0;
+        const cx<T> n0 = a0p[(size_t)(pn + q) * K], n1 = two ? a0p[(size_t)(pn + q) * K + 16] : mk<T>(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g < n_cg) {
+            const cx<T> yv = Yl[(g * 8 + fsub) * YS + p0 + q];
+            const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
+            const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
+            acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc[0][g], 0, 0, 0);
+            acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc[0][g], 0, 0, 0);
+            acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc[1][g], 0, 0, 0);
+            acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc[1][g], 0, 0, 0);
+          }
         }
+        a0 = n0; a1 = n1;
       }
-      // C row = 4*q + r (atom within tile), column = i16 = (frame fcol, re/im cim)
       float* c0f = (float*)c0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        c0f[2 * (fcol * K + tile0 * 16 + 4 * q + r) + cim] = acc0[r];
-        if (two) c0f[2 * (fcol * K + (tile0 + 1) * 16 + 4 * q + r) + cim] = acc1[r];
+      for (int g = 0; g < 4; ++g) {
+        if (g < n_cg) {
+          const int fcol = g * 8 + fsub;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c0f[2 * (fcol * K + tile0 * 16 + 4 * q + r) + cim] = acc[0][g][r];
+            if (two) c0f[2 * (fcol * K + (tile0 + 1) * 16 + 4 * q + r) + cim] = acc[1][g][r];
+          }
+        }
       }
     }
   } else {
-    for (int i = tid; i < OMP_FB * K; i += 256) {
+    for (int i = tid; i < FB * K; i += 256) {
       const int f = i / K, k = i - f * K;
       cx<T> acc = mk<T>(0, 0);
       for (int p = 0; p < np; ++p) acc = acc + P.sct[(size_t)p * K + k] * Yl[f * YS + p];
@@ -313,117 +346,227 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     }
   }
   __syncthreads();
-  // ---- one wavefront per frame: OMP iterations (wave-private state, no workgroup barrier below)
-  unsigned char* wb = smem + lay.off_wave + wave * lay.wave_bytes;
-  c64* Lm = (c64*)wb;                       // [taps][taps] lower Cholesky factor of the Gram
-  c64* zv = Lm + (size_t)taps * taps;       // L z = b
-  c64* xv = zv + taps;                      // L^H x = z
+  // ---- stage 2: FPW frames per wavefront side by side (no workgroup barrier below)
+  const int LPF = 64 / FPW;                      // lanes per frame
+  const int grp = lane / LPF, sl = lane - grp * LPF;
+  const int fi = wave * FPW + grp;               // frame slot inside the workgroup
+  const int64_t f = f0 + fi;
+  const bool live = f < n_frames;
+  unsigned char* sb = smem + lay.off_state + (size_t)fi * lay.state_bytes;
+  cx<T>* Lm = (cx<T>*)sb;                        // [taps][taps] lower Cholesky factor; diagonal holds 1/L[j][j]
+  cx<T>* zv = Lm + (size_t)taps * taps;          // L z = b
+  cx<T>* xv = zv + taps;                         // L^H x = z
   int* picks = (int*)(xv + taps);
-  int* ctl = picks + ((taps + 1) & ~1);     // [0] picks made, [1] stopped, [2..3] residual energy (double)
-  for (int fi = wave; fi < OMP_FB; fi += 4) {
-    const int64_t f = f0 + fi;
-    if (f >= n_frames) break;
-    const cx<T>* yf = Yl + fi * YS;
-    const cx<T>* cf = c0 + fi * K;
-    double ynorm = 0;
-    for (int p = lane; p < np; p += 64) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
+  int* ctl = picks + ((taps + 1) & ~1);          // [0] picks made, [1] stopped, [2..3] residual energy (double)
+  const cx<T>* yf = Yl + fi * YS;
+  const cx<T>* cf = c0 + fi * K;
+  double ynorm = 0;
+  for (int p = sl; p < np; p += LPF) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
+  for (int off = LPF >> 1; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
+  if (sl == 0) { ctl[0] = 0; ctl[1] = live ? 0 : 1; ((double*)(ctl + 2))[0] = ynorm; }
+  wave_sync();
+  const T g0 = gl[0].x;
+  constexpr int RT = 8;
+  if (taps <= RT) {
+    // ---- register-resident OMP (dominant_taps <= 8): the iteration loop is fully unrolled, so the number
+    // of picks made so far is the compile-time constant `it` and every index into L / z / x / pk is
+    // static.  All lanes of a frame's group compute the tiny solve redundantly from group-uniform
+    // inputs: no serial lane, no LDS state, no broadcast.  L is the lower Cholesky factor of the Gram
+    // of the picked atoms with 1/L[j][j] on the diagonal (tri(i,j) = i(i+1)/2 + j).
+    int pk[RT];
+    cx<T> xr[RT], zr[RT], Lr[RT * (RT + 1) / 2];
+    T Ld[RT];                                      // 1 / L[j][j]
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
-    double rho_prev = ynorm;
+    for (int i = 0; i < RT; ++i) { pk[i] = -1; xr[i] = zr[i] = mk<T>(0, 0); Ld[i] = T(0); }
+    bool active = live;
     int n = 0;
-    bool stopped = false;
-    for (int it = 0; it < taps && !stopped; ++it) {
+    double rho = ynorm;
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+      if (it >= ((P.dbg & 2) ? 0 : taps)) break;
       // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
       float bs = -1.0f;
       int bi = 0x7fffffff;
-      for (int k = lane; k < K; k += 64) {
+      for (int k = sl; k < K; k += LPF) {
         cx<T> c = cf[k];
-        for (int qq = 0; qq < n; ++qq) {
-          const int d = picks[qq] - k;
-          const c64 gq = d >= 0 ? gl[d] : conj(gl[-d]);
-          const c64 t = gq * xv[qq];
-          c = c - mk<T>((T)t.x, (T)t.y);
+#pragma unroll
+        for (int qq = 0; qq < it; ++qq) {
+          const int d = pk[qq] - k;
+          const cx<T> gv = gl[d >= 0 ? d : -d];
+          c = c - (d >= 0 ? gv : conj(gv)) * xr[qq];
         }
         const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
         if (sc > bs) { bs = sc; bi = k; }          // ascending k inside a lane: strict > keeps the first
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
+      for (int off = LPF >> 1; off > 0; off >>= 1) {
         const float os = __shfl_xor(bs, off, 64);
         const int oi = __shfl_xor(bi, off, 64);
         if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
       }
-      const int kp = bi < K ? bi : 0;                // all-NaN scores: MATLAB max returns index 1
-      if (lane == 0) {
+      const int kp = bi < K ? bi : 0;              // all-NaN scores: MATLAB max returns index 1
+      if (active) {
         int dup = -1;
-        for (int qq = 0; qq < n; ++qq) if (picks[qq] == kp) dup = qq;
+#pragma unroll
+        for (int qq = 0; qq < it; ++qq) if (pk[qq] == kp) dup = qq;
         if (dup >= 0) {
           // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
-          const c64 half{xv[dup].x * 0.5, xv[dup].y * 0.5};
-          xv[dup] = half; xv[n] = half; picks[n] = kp;
-          ctl[0] = n + 1; ctl[1] = 1;
+          cx<T> half = mk<T>(0, 0);
+#pragma unroll
+          for (int qq = 0; qq < it; ++qq) if (qq == dup) { xr[qq] = xr[qq] * (T)0.5; half = xr[qq]; }
+          xr[it] = half;
+          pk[it] = kp;
+          n = it + 1;
+          active = false;
         } else {
-          picks[n] = kp;
-          // new Cholesky row: G[n][j] = a_n^H a_j = gram[idx_j - idx_n]
-          double dd = gl[0].x;
-          for (int jq = 0; jq < n; ++jq) {
-            const int d = picks[jq] - kp;
-            c64 s = d >= 0 ? gl[d] : conj(gl[-d]);
-            for (int k2 = 0; k2 < jq; ++k2) s = s - mulc(Lm[n * taps + k2], Lm[jq * taps + k2]);
-            const double ljj = Lm[jq * taps + jq].x;
-            const c64 l = c64{s.x / ljj, s.y / ljj};
-            Lm[n * taps + jq] = l;
+          pk[it] = kp;
+          // new Cholesky row: G[it][j] = a_it^H a_j = gram[idx_j - idx_it]
+          T dd = g0;
+#pragma unroll
+          for (int jq = 0; jq < it; ++jq) {
+            const int d = pk[jq] - kp;
+            cx<T> sgm = d >= 0 ? gl[d] : conj(gl[-d]);
+#pragma unroll
+            for (int k2 = 0; k2 < jq; ++k2) sgm = sgm - mulc(Lr[it * (it + 1) / 2 + k2], Lr[jq * (jq + 1) / 2 + k2]);
+            const cx<T> l = sgm * Ld[jq];
+            Lr[it * (it + 1) / 2 + jq] = l;
             dd -= norm2(l);
           }
-          const double lnn = sqrt(dd);
-          Lm[n * taps + n] = c64{lnn, 0};
-          // forward substitution (only the new entry changes): b_n = a_n^H y = c0[kp]
-          c64 s{(double)cf[kp].x, (double)cf[kp].y};
-          for (int k2 = 0; k2 < n; ++k2) s = s - Lm[n * taps + k2] * zv[k2];
-          zv[n] = c64{s.x / lnn, s.y / lnn};
+          const T inv_lnn = T(1) / sqrt(dd);
+          Ld[it] = inv_lnn;
+          // forward substitution (only the new entry changes): b_it = a_it^H y = c0[kp]
+          cx<T> sz = cf[kp];
+#pragma unroll
+          for (int k2 = 0; k2 < it; ++k2) sz = sz - Lr[it * (it + 1) / 2 + k2] * zr[k2];
+          const cx<T> zn = sz * inv_lnn;
+          zr[it] = zn;
           // back substitution L^H x = z
-          for (int r = n; r >= 0; --r) {
-            c64 a = zv[r];
-            for (int k2 = r + 1; k2 <= n; ++k2) a = a - mulc(xv[k2], Lm[k2 * taps + r]);
-            const double l = Lm[r * taps + r].x;
-            xv[r] = c64{a.x / l, a.y / l};
+#pragma unroll
+          for (int r = it; r >= 0; --r) {
+            cx<T> acc = zr[r];
+#pragma unroll
+            for (int k2 = r + 1; k2 <= it; ++k2) acc = acc - mulc(xr[k2], Lr[k2 * (k2 + 1) / 2 + r]);
+            xr[r] = acc * Ld[r];
           }
           // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
-          const double num = norm2(zv[n]);
-          int stop = 0;
-          if (it >= 1 && (!(num > 0.0) || sqrt(num / rho_prev) < 1e-2)) stop = 1;
-          ((double*)(ctl + 2))[0] = rho_prev - num;
-          ctl[0] = n + 1;
-          ctl[1] = stop;
+          const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
+          if (it >= 1 && (!(num > 0.0) || sqrt(num / rho) < 1e-2)) active = false;
+          rho -= num;
+          n = it + 1;
         }
       }
-      wave_sync();
-      n = ctl[0];
-      stopped = ctl[1] != 0;
-      rho_prev = ((double*)(ctl + 2))[0];
-      wave_sync();
     }
     // est_fade_chan(index(i1)) = x(i1): a later duplicate overwrites an earlier one (:31-33)
-    if (lane < taps) {
-      int idx = -1;
-      c64 xo{0, 0};
-      if (lane < n) {
-        idx = picks[lane];
-        xo = xv[lane];
-        for (int q2 = lane + 1; q2 < n; ++q2) if (picks[q2] == idx) xo = c64{0, 0};
+    if (live && sl == 0) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        if (t < taps) {
+          int idx = -1;
+          c64 xo{0, 0};
+          if (t < n) {
+            idx = pk[t];
+            xo = c64{(double)xr[t].x, (double)xr[t].y};
+#pragma unroll
+            for (int q2 = t + 1; q2 < RT; ++q2) if (q2 < n && pk[q2] == idx) xo = c64{0, 0};
+          }
+          P.tap_idx[f * taps + t] = idx;
+          P.tap_x[f * taps + t] = xo;
+        }
       }
-      P.tap_idx[f * taps + lane] = idx;
-      P.tap_x[f * taps + lane] = xo;
+    }
+    return;
+  }
+  // ---- generic path (more than 8 taps): per-frame state in LDS, serial solve on the group's first lane
+  for (int it = 0; it < ((P.dbg & 2) ? 0 : taps); ++it) {
+    const int n = ctl[0];
+    const bool active = ctl[1] == 0;
+    // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
+    float bs = -1.0f;
+    int bi = 0x7fffffff;
+    if (active) {
+      for (int k = sl; k < K; k += LPF) {
+        cx<T> c = cf[k];
+        for (int qq = 0; qq < n; ++qq) {
+          const int d = picks[qq] - k;
+          const cx<T> gv = gl[d >= 0 ? d : -d];
+          c = c - (d >= 0 ? gv : conj(gv)) * xv[qq];
+        }
+        const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
+        if (sc > bs) { bs = sc; bi = k; }
+      }
+    }
+    for (int off = LPF >> 1; off > 0; off >>= 1) {
+      const float os = __shfl_xor(bs, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+    }
+    const int kp = bi < K ? bi : 0;                // all-NaN scores: MATLAB max returns index 1
+    if (sl == 0 && active) {
+      int dup = -1;
+      for (int qq = 0; qq < n; ++qq) if (picks[qq] == kp) dup = qq;
+      if (dup >= 0) {
+        // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
+        const cx<T> half = xv[dup] * (T)0.5;
+        xv[dup] = half; xv[n] = half; picks[n] = kp;
+        ctl[0] = n + 1; ctl[1] = 1;
+      } else {
+        picks[n] = kp;
+        // new Cholesky row: G[n][j] = a_n^H a_j = gram[idx_j - idx_n]
+        T dd = g0;
+        for (int jq = 0; jq < n; ++jq) {
+          const int d = picks[jq] - kp;
+          cx<T> s = d >= 0 ? gl[d] : conj(gl[-d]);
+          for (int k2 = 0; k2 < jq; ++k2) s = s - mulc(Lm[n * taps + k2], Lm[jq * taps + k2]);
+          const cx<T> l = s * Lm[jq * taps + jq].x;             // times 1/L[jq][jq]
+          Lm[n * taps + jq] = l;
+          dd -= norm2(l);
+        }
+        const T inv_lnn = T(1) / sqrt(dd);
+        Lm[n * taps + n] = mk<T>(inv_lnn, 0);
+        // forward substitution (only the new entry changes): b_n = a_n^H y = c0[kp]
+        cx<T> s = cf[kp];
+        for (int k2 = 0; k2 < n; ++k2) s = s - Lm[n * taps + k2] * zv[k2];
+        const cx<T> zn = s * inv_lnn;
+        zv[n] = zn;
+        // back substitution L^H x = z
+        for (int r = n; r >= 0; --r) {
+          cx<T> a = zv[r];
+          for (int k2 = r + 1; k2 <= n; ++k2) a = a - mulc(xv[k2], Lm[k2 * taps + r]);
+          xv[r] = a * Lm[r * taps + r].x;
+        }
+        // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
+        const double rho_prev = ((double*)(ctl + 2))[0];
+        const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
+        int stop = 0;
+        if (it >= 1 && (!(num > 0.0) || sqrt(num / rho_prev) < 1e-2)) stop = 1;
+        ((double*)(ctl + 2))[0] = rho_prev - num;
+        ctl[0] = n + 1;
+        ctl[1] = stop;
+      }
     }
     wave_sync();
+  }
+  // est_fade_chan(index(i1)) = x(i1): a later duplicate overwrites an earlier one (:31-33)
+  const int n = ctl[0];
+  if (live) {
+    for (int t = sl; t < taps; t += LPF) {
+      int idx = -1;
+      c64 xo{0, 0};
+      if (t < n) {
+        idx = picks[t];
+        xo = c64{(double)xv[t].x, (double)xv[t].y};
+        for (int q2 = t + 1; q2 < n; ++q2) if (picks[q2] == idx) xo = c64{0, 0};
+      }
+      P.tap_idx[f * taps + t] = idx;
+      P.tap_x[f * taps + t] = xo;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NW, bool PRUNE2>
-__global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+template <typename T, int NW, bool PRUNE2, bool PREFETCH>
+__global__ __launch_bounds__(64 * NW, PREFETCH ? 4 : 5) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
                                                              uint32_t* __restrict__ errors_out,
@@ -458,7 +601,7 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
   cx<T> v[8], nx[8];
   for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
     const cx<T>* frx = rx + f * (int64_t)Lsym * P.n_symb;
-    if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane);
+    if constexpr (PREFETCH) { if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane); }
     if (gid == 0) sh_err = 0;
     // ---- H = fft(h)(1..N_carrier) from the taps; G = 1 ./ H           (OMP_estimate.m:36, equalize_signal.m:6)
     if (gid < taps) {
@@ -492,9 +635,13 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
       if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
     // ---- symbols 2..S
     for (int s = 1; s < P.n_symb; ++s) {
+      if constexpr (PREFETCH) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = nx[e];
-      if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
+        for (int e = 0; e < 8; ++e) v[e] = nx[e];
+        if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
+      } else {
+        frame_load<T, NW>(v, frx + (int64_t)s * Lsym + P.t_guard, gid, lane);
+      }
       if constexpr (NW > 1) {
         dif_stage<T, NW>(v, dt);
         __syncthreads();                 // every wavefront has finished gathering the previous symbol
@@ -575,6 +722,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   P.prole = (const int16_t*)pv.d_prole; P.drole = (const int16_t*)pv.d_drole;
   P.pilots = (const cx<T>*)pv.d_pilots; P.sct = (const cx<T>*)pv.d_sct; P.gram = (const c64*)pv.d_gram;
   P.tw = (const cx<T>*)tw;
+  { const char* e = getenv("OFDM_FAST_SKIP"); P.dbg = e ? atoi(e) : 0; }
   // workspace (grown on demand, kept by the plan)
   if (*pv.ws_frames < n_frames) {
     void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx};
@@ -604,8 +752,8 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   {
     const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
     OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
-    const unsigned grid = cdiv_u(n_frames, OMP_FB);
-    const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) &&
+    const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
+    const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) && lay.fpw >= 2 &&
                       !getenv("OFDM_OMP_NO_MFMA");
     if (mfma) {
       if constexpr (std::is_same<T, float>::value) {
@@ -628,11 +776,20 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     // occupancy: 128 VGPRs -> 4 waves per SIMD; a workgroup puts NW/4 waves on every SIMD
     const int by_vgpr = std::max(1, 16 / NW);
     const int per_cu = std::max(1, std::min(by_vgpr, (int)(156 * 1024 / (dyn + 1024))));
-    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
-    OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
-                       n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
-                       (int32_t*)idx_out, tab);
+    const bool prefetch = !getenv("OFDM_FAST_NOPREFETCH");
+    const int per_cu2 = prefetch ? per_cu : std::max(1, std::min(std::max(1, 20 / NW), (int)(156 * 1024 / (dyn + 1024))));
+    const unsigned grid2 = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu2);
+    if (prefetch) {
+      OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2, true>), dim3(grid2), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
+                         n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
+                         (int32_t*)idx_out, tab);
+    } else {
+      OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2, false>), dim3(grid2), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
+                         n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
+                         (int32_t*)idx_out, tab);
+    }
     OFDM_TRY(check_launch("rx_symbols_kernel"));
   }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
