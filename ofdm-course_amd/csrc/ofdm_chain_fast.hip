@@ -65,15 +65,55 @@ __device__ __forceinline__ void dft8_first2(cx<T> (&v)[8]) {
   v[1] = (b0 + b2) + (b1 + b3);
 }
 
+// Eight ds_read_b64 at base + e*STRIDE elements, issued back to back and waited for once.
+// Hand-issued because the compiler fuses neighbouring b64 reads into ds_read2_b64 / ds_read2st64_b64,
+// which move half the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table: 128 vs 256 B/clk).
+// One asm statement: the outputs only become valid at its trailing s_waitcnt.
+template <int STRIDE, bool ASM>
+__device__ __forceinline__ void lds_read8(cx<float> (&v)[8], const cx<float>* base) {
+  if constexpr (ASM) {
+    const unsigned a = (unsigned)(uintptr_t)base;            // LDS aperture: low 32 bits = LDS byte address
+    unsigned long long r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64 %0, %8 offset:%9\n\t"
+        "ds_read_b64 %1, %8 offset:%10\n\t"
+        "ds_read_b64 %2, %8 offset:%11\n\t"
+        "ds_read_b64 %3, %8 offset:%12\n\t"
+        "ds_read_b64 %4, %8 offset:%13\n\t"
+        "ds_read_b64 %5, %8 offset:%14\n\t"
+        "ds_read_b64 %6, %8 offset:%15\n\t"
+        "ds_read_b64 %7, %8 offset:%16\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(a), "n"(0 * STRIDE * 8), "n"(1 * STRIDE * 8), "n"(2 * STRIDE * 8), "n"(3 * STRIDE * 8),
+          "n"(4 * STRIDE * 8), "n"(5 * STRIDE * 8), "n"(6 * STRIDE * 8), "n"(7 * STRIDE * 8)
+        : "memory");
+    const unsigned long long r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e].x = __uint_as_float((unsigned)r[e]);
+      v[e].y = __uint_as_float((unsigned)(r[e] >> 32));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = base[STRIDE * e];
+  }
+}
+template <int STRIDE, bool ASM>
+__device__ __forceinline__ void lds_read8(cx<double> (&v)[8], const cx<double>* base) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = base[STRIDE * e];
+}
+
 // forward 512-point FFT inside one wavefront.  v[e] <-> y[lane + 64 e] on entry; on exit
 // v[t] = Y[lane + 64 t]  (t < 2 only when PRUNE2).  lw = this wavefront's private LDS region.
 // Padded addressing wpad(i) = i + i/8, written as one base per access pattern + immediates:
 //   scatter A : wpad(8 lane + t)            = 9 lane + t
 //   gather    : wpad(lane + 64 e)           = lane + lane/8 + 72 e
 //   scatter B : wpad(64 (lane/8) + lane%8 + 8 t) = 72 (lane/8) + lane%8 + 9 t
-template <typename T, bool PRUNE2>
-__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T>* __restrict__ twl,
-                                            cx<T>* __restrict__ lw) {
+template <typename T, bool PRUNE2, bool TWB_REG = true, bool ASMRD = false>
+__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T> (&twb)[7],
+                                            const cx<T>* __restrict__ twl, cx<T>* __restrict__ lw) {
   cx<T>* const sa = lw + 9 * lane;
   cx<T>* const ga = lw + lane + (lane >> 3);
   cx<T>* const sb = lw + 72 * (lane >> 3) + (lane & 7);
@@ -81,17 +121,15 @@ __device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T>
 #pragma unroll
   for (int t = 0; t < 8; ++t) sa[t] = v[t];
   wave_sync();
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
+  lds_read8<72, ASMRD>(v, ga);
   wave_sync();
 #pragma unroll
-  for (int t = 1; t < 8; ++t) v[t] = v[t] * twl[(t - 1) * 64 + lane];
+  for (int t = 1; t < 8; ++t) v[t] = v[t] * (TWB_REG ? twb[t - 1] : twl[(t - 1) * 64 + lane]);
   dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
   for (int t = 0; t < 8; ++t) sb[9 * t] = v[t];
   wave_sync();
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = ga[72 * e];
+  lds_read8<72, ASMRD>(v, ga);
   wave_sync();
 #pragma unroll
   for (int t = 1; t < 8; ++t) v[t] = v[t] * twl[448 + (t - 1) * 64 + lane];
@@ -159,10 +197,9 @@ __device__ __forceinline__ void dif_scatter(const cx<T> (&v)[8], int gid, cx<T>*
 #pragma unroll
     for (int b = 0; b < BPT; ++b) ex[s * WAVE_LDS_ELEMS + gid * BPT + b] = v[b * NW + s];
 }
-template <typename T>
+template <typename T, bool ASMRD = false>
 __device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, const cx<T>* __restrict__ ex) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = ex[wave * WAVE_LDS_ELEMS + lane + 64 * e];
+  lds_read8<64, ASMRD>(v, ex + wave * WAVE_LDS_ELEMS + lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,6 +237,9 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
   DifTw<T, NW> dt;
   wave_tw_fill<T, NW>(twl, P.tw);
   dif_tw_init<T, NW>(dt, gid, P.tw);
+  cx<T> twb[7];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) twb[t - 1] = P.tw[(t * (lane & 7) * 8) * NW];
   __syncthreads();
   int kk[NOUT], pp[NOUT];
 #pragma unroll
@@ -218,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
       __syncthreads();
       dif_gather<T>(v, wave, lane, ex);
     }
-    wave_fft512<T, PRUNE2>(v, lane, twl, lwv + wave * WAVE_LDS_ELEMS);
+    wave_fft512<T, PRUNE2>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) {
       if (kk[t] < P.n_carrier) {
@@ -565,8 +605,8 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // ---------------------------------------------------------------------------------------------
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NW, bool PRUNE2, bool PREFETCH>
-__global__ __launch_bounds__(64 * NW, PREFETCH ? 4 : 5) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+template <typename T, int NW, bool PRUNE2, int VAR>
+__global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
                                                              uint32_t* __restrict__ errors_out,
@@ -586,6 +626,9 @@ __global__ __launch_bounds__(64 * NW, PREFETCH ? 4 : 5) void rx_symbols_kernel(F
   DifTw<T, NW> dt;
   wave_tw_fill<T, NW>(twl, P.tw);
   dif_tw_init<T, NW>(dt, gid, P.tw);
+  cx<T> twb[7];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) twb[t - 1] = P.tw[(t * (lane & 7) * 8) * NW];
   int kk[NOUT], dd[NOUT];
 #pragma unroll
   for (int t = 0; t < NOUT; ++t) {
@@ -601,7 +644,7 @@ __global__ __launch_bounds__(64 * NW, PREFETCH ? 4 : 5) void rx_symbols_kernel(F
   cx<T> v[8], nx[8];
   for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
     const cx<T>* frx = rx + f * (int64_t)Lsym * P.n_symb;
-    if constexpr (PREFETCH) { if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane); }
+    if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane);
     if (gid == 0) sh_err = 0;
     // ---- H = fft(h)(1..N_carrier) from the taps; G = 1 ./ H           (OMP_estimate.m:36, equalize_signal.m:6)
     if (gid < taps) {
@@ -635,21 +678,17 @@ __global__ __launch_bounds__(64 * NW, PREFETCH ? 4 : 5) void rx_symbols_kernel(F
       if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
     // ---- symbols 2..S
     for (int s = 1; s < P.n_symb; ++s) {
-      if constexpr (PREFETCH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = nx[e];
-        if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
-      } else {
-        frame_load<T, NW>(v, frx + (int64_t)s * Lsym + P.t_guard, gid, lane);
-      }
+      for (int e = 0; e < 8; ++e) v[e] = nx[e];
+      if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
       if constexpr (NW > 1) {
         dif_stage<T, NW>(v, dt);
         __syncthreads();                 // every wavefront has finished gathering the previous symbol
         dif_scatter<T, NW>(v, gid, ex);
         __syncthreads();
-        dif_gather<T>(v, wave, lane, ex);
+        dif_gather<T, (VAR & 1) != 0>(v, wave, lane, ex);
       }
-      wave_fft512<T, PRUNE2>(v, lane, twl, lwv + wave * WAVE_LDS_ELEMS);
+      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
       for (int t = 0; t < NOUT; ++t)
         if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
@@ -776,20 +815,17 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     // occupancy: 128 VGPRs -> 4 waves per SIMD; a workgroup puts NW/4 waves on every SIMD
     const int by_vgpr = std::max(1, 16 / NW);
     const int per_cu = std::max(1, std::min(by_vgpr, (int)(156 * 1024 / (dyn + 1024))));
-    const bool prefetch = !getenv("OFDM_FAST_NOPREFETCH");
-    const int per_cu2 = prefetch ? per_cu : std::max(1, std::min(std::max(1, 20 / NW), (int)(156 * 1024 / (dyn + 1024))));
-    const unsigned grid2 = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu2);
-    if (prefetch) {
-      OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2, true>), dim3(grid2), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
-                         n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
-                         (int32_t*)idx_out, tab);
-    } else {
-      OFDM_HIP(hipFuncSetAttribute((const void*)rx_symbols_kernel<T, NW, PRUNE2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      hipLaunchKernelGGL((rx_symbols_kernel<T, NW, PRUNE2, false>), dim3(grid2), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx,
-                         n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out,
-                         (int32_t*)idx_out, tab);
-    }
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
+    // experiment selector (A/B inside one process): 1 = hand-issued ds_read_b64 gathers, 0 = compiler's ds_read2
+    static const int var = [] { const char* e = getenv("OFDM_FAST_VARIANT"); return e ? atoi(e) : 1; }();
+    auto launch = [&](auto kern) -> int {
+      OFDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx, n_frames, (uint32_t*)bits,
+                         (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
+      return OFDM_OK;
+    };
+    if (var == 0) OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0>));
+    else OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 1>));
     OFDM_TRY(check_launch("rx_symbols_kernel"));
   }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
