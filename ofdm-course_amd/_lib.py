@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libofdm_mi355x.so")
+LIB_PATH = os.environ.get("OFDM_LIB_PATH") or os.path.join(HERE, "libofdm_mi355x.so")
 
 OFDM_F32, OFDM_F64, OFDM_HOST, OFDM_DEVICE = 0, 1, 0, 2
 OFDM_SOFT_ACF_FALLBACK = 1

@@ -248,9 +248,12 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, c
     pp[t] = kk[t] < P.n_carrier ? (int)P.prole[kk[t]] : -1;
   }
   const int64_t L = (int64_t)(N + P.t_guard) * P.n_symb;
-  cx<T> v[8];
+  cx<T> v[8], nx[8];
+  if ((int64_t)blockIdx.x < n_frames) frame_load<T, NW>(nx, rx + (int64_t)blockIdx.x * L + P.t_guard, gid, lane);
   for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
-    frame_load<T, NW>(v, rx + f * L + P.t_guard, gid, lane);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = nx[e];
+    if (f + gridDim.x < n_frames) frame_load<T, NW>(nx, rx + (f + gridDim.x) * L + P.t_guard, gid, lane);   // next frame in flight
     if constexpr (NW > 1) {
       dif_stage<T, NW>(v, dt);
       __syncthreads();
@@ -782,7 +785,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
   // kernel 1
   {
-    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * 8);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * std::max(1, 16 / NW));
     hipLaunchKernelGGL((rx_pilot_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), 0, st, P, (const cx<T>*)rx, n_frames);
     OFDM_TRY(check_launch("rx_pilot_kernel"));
   }
@@ -812,14 +815,20 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS) +
                        (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
     OFDM_ARG(dyn <= 150 * 1024, "rx_chain_task5: symbol stage needs %zu bytes of LDS", dyn);
-    // occupancy: 128 VGPRs -> 4 waves per SIMD; a workgroup puts NW/4 waves on every SIMD
-    const int by_vgpr = std::max(1, 16 / NW);
-    const int per_cu = std::max(1, std::min(by_vgpr, (int)(156 * 1024 / (dyn + 1024))));
-    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
+    // persistent grid = CUs x resident workgroups per CU (from the occupancy API: registers + LDS);
+    // workgroups are independent, so an optimistic answer only queues a few of them.
+    auto blocks_per_cu = [&](auto kern) -> int {
+      int nb = 0;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, dyn) != hipSuccess || nb < 1) nb = 1;
+      if (const char* e = getenv("OFDM_FAST_WG_PER_CU")) nb = std::max(1, atoi(e));
+      return std::min(nb, 8);
+    };
     // experiment selector (A/B inside one process): 1 = hand-issued ds_read_b64 gathers, 0 = compiler's ds_read2
     static const int var = [] { const char* e = getenv("OFDM_FAST_VARIANT"); return e ? atoi(e) : 1; }();
     auto launch = [&](auto kern) -> int {
-      OFDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      static const int per_cu = blocks_per_cu(kern);       // per instantiation
+      const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx, n_frames, (uint32_t*)bits,
                          (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
       return OFDM_OK;
