@@ -366,7 +366,7 @@ static int launch_chain(const ofdm_rx_plan* pl, const void* tw, const void* rx, 
   constexpr int FPW = fft_xforms_per_wg(N);
   chain_layout<T>(P, N, pl->bps);
   const size_t dyn = (size_t)P.group_bytes * FPW;
-  OFDM_ARG(dyn <= 120 * 1024, "rx_chain_task5: configuration needs %zu bytes of LDS", dyn);
+  OFDM_ARG(dyn <= 158 * 1024, "rx_chain_task5: configuration needs %zu bytes of LDS (limit 158 KiB; use fp32 or a smaller frame)", dyn);
   OFDM_HIP(hipFuncSetAttribute((const void*)rx_chain_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   hipLaunchKernelGGL((rx_chain_kernel<T, N>), dim3(cdiv_u(n_frames, FPW)), dim3(fft_wg_threads(N)), dyn, ctx().stream,
                      P, (const cx<T>*)rx, n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs,

@@ -679,22 +679,26 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
 #pragma unroll
     for (int t = 0; t < NOUT; ++t)
       if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
-    // ---- symbols 2..S
+    // ---- symbols 2..S (the next symbol's samples are in flight while this one is transformed; alternating two
+    //      register sets instead of copying was measured slower: it costs a workgroup of occupancy)
+    auto do_symbol = [&](cx<T> (&cur)[8], cx<T> (&nxt)[8], int s) {
+      if (s + 1 < P.n_symb) frame_load<T, NW>(nxt, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
+      if constexpr (NW > 1) {
+        dif_stage<T, NW>(cur, dt);
+        __syncthreads();                 // every wavefront has finished its previous transform (region reuse)
+        dif_scatter<T, NW>(cur, gid, ex);
+        __syncthreads();
+        dif_gather<T, (VAR & 1) != 0>(cur, wave, lane, ex);
+      }
+      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(cur, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t)
+        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, cur[t] * geq[t]);
+    };
     for (int s = 1; s < P.n_symb; ++s) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = nx[e];
-      if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
-      if constexpr (NW > 1) {
-        dif_stage<T, NW>(v, dt);
-        __syncthreads();                 // every wavefront has finished gathering the previous symbol
-        dif_scatter<T, NW>(v, gid, ex);
-        __syncthreads();
-        dif_gather<T, (VAR & 1) != 0>(v, wave, lane, ex);
-      }
-      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
-#pragma unroll
-      for (int t = 0; t < NOUT; ++t)
-        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
+      do_symbol(v, nx, s);
     }
     __syncthreads();
     // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
