@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,28 +79,33 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.force_device is None else args.force_device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the collective's tensors live
 
     import ofdm_course_amd as ofdm
     from ofdm_course_amd import frames as fr
 
-    ofdm.init(local_rank)
+    ofdm.init(dev_index)
     cfg = fr.config_M()
     _, bps = ofdm.constellation_func(cfg.Constellation)
     F = args.frames
     f0 = rank * F
     data = fr.make_frames(cfg, ofdm, F, seed=1, precision=args.precision, device=dev, frame0=f0)
-    plan = fr.make_plan(cfg, ofdm, precision=args.precision, device=local_rank)
+    plan = fr.make_plan(cfg, ofdm, precision=args.precision, device=dev_index)
     ref = torch.from_numpy(data["packed"]).to(dev)
     rx = data["rx"]
     torch.cuda.synchronize()
     frame_bits = data["bits"].shape[1]
-    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    counters = torch.zeros(2, dtype=torch.int64, device=cdev)
 
     def step():
         out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
@@ -139,7 +146,7 @@ def main():
     plan.set_timing(False)
     kms = np.mean(np.array(kms), axis=0)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
