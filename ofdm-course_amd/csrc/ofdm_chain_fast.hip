@@ -226,7 +226,7 @@ struct FastParams {
 // kernel 1: symbol 1 -> stash + Y
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NW, bool PRUNE2>
-__global__ __launch_bounds__(64 * NW, 4) void rx_pilot_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 2) void rx_pilot_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                            int64_t n_frames) {
   constexpr int N = 512 * NW;
   constexpr int NOUT = PRUNE2 ? 2 : 8;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NW, bool PRUNE2, int VAR>
-__global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
                                                              uint32_t* __restrict__ errors_out,
@@ -679,26 +679,24 @@ __global__ __launch_bounds__(64 * NW, 4) void rx_symbols_kernel(FastParams<T> P,
 #pragma unroll
     for (int t = 0; t < NOUT; ++t)
       if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
-    // ---- symbols 2..S (the next symbol's samples are in flight while this one is transformed; alternating two
-    //      register sets instead of copying was measured slower: it costs a workgroup of occupancy)
-    auto do_symbol = [&](cx<T> (&cur)[8], cx<T> (&nxt)[8], int s) {
-      if (s + 1 < P.n_symb) frame_load<T, NW>(nxt, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
-      if constexpr (NW > 1) {
-        dif_stage<T, NW>(cur, dt);
-        __syncthreads();                 // every wavefront has finished its previous transform (region reuse)
-        dif_scatter<T, NW>(cur, gid, ex);
-        __syncthreads();
-        dif_gather<T, (VAR & 1) != 0>(cur, wave, lane, ex);
-      }
-      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(cur, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
-#pragma unroll
-      for (int t = 0; t < NOUT; ++t)
-        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, cur[t] * geq[t]);
-    };
+    // ---- symbols 2..S: the next symbol's samples are in flight while this one is transformed.  Measured and
+    //      rejected: alternating two register sets instead of copying (-1 workgroup of occupancy), two symbols in
+    //      flight (119 VGPRs, 11 % slower) -- the kernel is not HBM-latency bound.
     for (int s = 1; s < P.n_symb; ++s) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = nx[e];
-      do_symbol(v, nx, s);
+      if (s + 1 < P.n_symb) frame_load<T, NW>(nx, frx + (int64_t)(s + 1) * Lsym + P.t_guard, gid, lane);
+      if constexpr (NW > 1) {
+        dif_stage<T, NW>(v, dt);
+        __syncthreads();                 // every wavefront has finished its previous transform (region reuse)
+        dif_scatter<T, NW>(v, gid, ex);
+        __syncthreads();
+        dif_gather<T, (VAR & 1) != 0>(v, wave, lane, ex);
+      }
+      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t)
+        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
     }
     __syncthreads();
     // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
