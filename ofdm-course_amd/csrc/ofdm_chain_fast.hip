@@ -226,7 +226,7 @@ struct FastParams {
 // kernel 1: symbol 1 -> stash + Y
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NW, bool PRUNE2>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 2) void rx_pilot_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_pilot_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                            int64_t n_frames) {
   constexpr int N = 512 * NW;
   constexpr int NOUT = PRUNE2 ? 2 : 8;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NW, bool PRUNE2, int VAR>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
                                                              uint32_t* __restrict__ errors_out,
