@@ -208,7 +208,6 @@ __device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, co
 template <typename T>
 struct FastParams {
   int n_symb, t_guard, n_carrier, np, nd, k_atoms, taps, frame_words, bps;
-  int dbg;                   // diagnostics only (env OFDM_FAST_SKIP)
   const int16_t* prole;      // [nfft] pilot position of a carrier or -1
   const int16_t* drole;      // [nfft] data position of a carrier or -1
   const cx<T>* pilots;       // [np]
@@ -327,9 +326,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
   for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
   __syncthreads();
   // ---- c0 = S^H Y
-  if (P.dbg & 1) {
-    for (int i = tid; i < FB * K; i += 256) c0[i] = mk<T>((T)(i & 7), (T)1);
-  } else if constexpr (MFMA) {
+  if constexpr (MFMA) {
     // real GEMM  C[K x 2 FB] = A[K x 2np] * B[2np x 2 FB]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
     // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
     // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 per 16x16 tile (real / imaginary parts of A).
@@ -426,7 +423,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     double rho = ynorm;
 #pragma unroll
     for (int it = 0; it < RT; ++it) {
-      if (it >= ((P.dbg & 2) ? 0 : taps)) break;
+      if (it >= taps) break;
       // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
       float bs = -1.0f;
       int bi = 0x7fffffff;
@@ -519,7 +516,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     return;
   }
   // ---- generic path (more than 8 taps): per-frame state in LDS, serial solve on the group's first lane
-  for (int it = 0; it < ((P.dbg & 2) ? 0 : taps); ++it) {
+  for (int it = 0; it < taps; ++it) {
     const int n = ctl[0];
     const bool active = ctl[1] == 0;
     // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
@@ -608,7 +605,16 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // ---------------------------------------------------------------------------------------------
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NW, bool PRUNE2, int VAR>
+// BA = bits per axis of a square QAM (2, 3, 4: the slicer thresholds become compile-time-indexed scalars;
+// with a run-time switch every variant's constants stay live and the kernel spills ~80 SGPRs to VGPR lanes),
+// BA = 0: any constellation through the generic decision function.
+template <typename T, int BA>
+__device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
+  if constexpr (BA == 0) return demap_decide(tab, z);
+  else return demap_square<T, BA>(tab, z);
+}
+
+template <typename T, int NW, bool PRUNE2, int BA>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
     // ---- symbol 1 from the stash
 #pragma unroll
     for (int t = 0; t < NOUT; ++t)
-      if (dd[t] >= 0) codes[dd[t]] = (uint8_t)demap_decide(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
+      if (dd[t] >= 0) codes[dd[t]] = (uint8_t)slice_symbol<T, BA>(tab, P.stash[f * P.n_carrier + kk[t]] * geq[t]);
     // ---- symbols 2..S: the next symbol's samples are in flight while this one is transformed.  Measured and
     //      rejected: alternating two register sets instead of copying (-1 workgroup of occupancy), two symbols in
     //      flight (119 VGPRs, 11 % slower) -- the kernel is not HBM-latency bound.
@@ -691,12 +697,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
         __syncthreads();                 // every wavefront has finished its previous transform (region reuse)
         dif_scatter<T, NW>(v, gid, ex);
         __syncthreads();
-        dif_gather<T, (VAR & 1) != 0>(v, wave, lane, ex);
+        dif_gather<T, true>(v, wave, lane, ex);
       }
-      wave_fft512<T, PRUNE2, true, (VAR & 1) != 0>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+      wave_fft512<T, PRUNE2, true, true>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
       for (int t = 0; t < NOUT; ++t)
-        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)demap_decide(tab, v[t] * geq[t]);
+        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)slice_symbol<T, BA>(tab, v[t] * geq[t]);
     }
     __syncthreads();
     // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
@@ -766,7 +772,6 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   P.prole = (const int16_t*)pv.d_prole; P.drole = (const int16_t*)pv.d_drole;
   P.pilots = (const cx<T>*)pv.d_pilots; P.sct = (const cx<T>*)pv.d_sct; P.gram = (const c64*)pv.d_gram;
   P.tw = (const cx<T>*)tw;
-  { const char* e = getenv("OFDM_FAST_SKIP"); P.dbg = e ? atoi(e) : 0; }
   // workspace (grown on demand, kept by the plan)
   if (*pv.ws_frames < n_frames) {
     void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx};
@@ -826,8 +831,6 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
       if (const char* e = getenv("OFDM_FAST_WG_PER_CU")) nb = std::max(1, atoi(e));
       return std::min(nb, 8);
     };
-    // experiment selector (A/B inside one process): 1 = hand-issued ds_read_b64 gathers, 0 = compiler's ds_read2
-    static const int var = [] { const char* e = getenv("OFDM_FAST_VARIANT"); return e ? atoi(e) : 1; }();
     auto launch = [&](auto kern) -> int {
       static const int per_cu = blocks_per_cu(kern);       // per instantiation
       const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
@@ -835,8 +838,13 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
                          (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
       return OFDM_OK;
     };
-    if (var == 0) OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0>));
-    else OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 1>));
+    const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
+    switch (ba) {
+      case 2: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 2>)); break;
+      case 3: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 3>)); break;
+      case 4: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 4>)); break;
+      default: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0>)); break;
+    }
     OFDM_TRY(check_launch("rx_symbols_kernel"));
   }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
