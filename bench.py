@@ -111,7 +111,9 @@ def main():
         out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
         return out
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one HIP event pair around the K timed steps, on the stream the library launches on (torch's current stream,
+    # bound with ofdm_set_stream): a pair per step would put two barrier packets (~11 us) between steps
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     out = None
     for _ in range(args.warmup):
         out = step()
@@ -123,19 +125,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev[0].record()
     for i in range(args.steps):
-        ev[i][0].record()
         out = step()
-        ev[i][1].record()
         if world > 1:
             counters[0] = out["errors"].sum()
             counters[1] = F * frame_bits
             dist.all_reduce(counters)          # the sweep's only collective: SUM of the error / bit counters
+    ev[1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps if args.steps else float("nan")
 
     # per-kernel durations (HIP events inside the library, on the launch stream), outside the timed region
     plan.set_timing(True)
@@ -178,6 +180,16 @@ def main():
             "kernels_ms": {"rx_pilot_kernel": float(kms[0]), "omp_batch_kernel": float(kms[1]),
                            "rx_symbols_kernel": float(kms[2])},
         }
+        # HBM bytes per step from the committed PMC passes (cannot be collected from inside this process): only
+        # quoted when this run is the workload those passes profiled
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "traffic.json")
+        if os.path.exists(tpath) and F == 8192 and args.precision == "fp32":
+            with open(tpath) as f:
+                tj = json.load(f)
+            res["roofline"]["traffic"] = tj["chain_bytes_per_step"]
+            res["roofline"]["algorithmic_bytes"] = b_sym * F * cfg.N_symb
+            res["roofline"]["traffic_source"] = ("profiles/round1/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                 "passes of this command (tools/pmc.sh), FETCH_SIZE doubled for gfx950")
         # dominant kernel alone: symbols 2..S of every frame + stash + bits out + reference bits in
         nd_, np_ = len(cfg.dataCarriers), len(cfg.pilotCarriers)
         b_dom = ((cfg.N_symb - 1) * (cfg.Nfft + cfg.T_guard) * csize + cfg.N_carrier * csize
