@@ -1,0 +1,87 @@
+"""Replay of `Task 5/Task5_part2.m`: NMSE and BER of LS / MMSE / MP / OMP equalisation against the pilot
+count, Monte-Carlo over channel draws (SURVEY.md 3.3 -- the shape of the north-star metric).
+
+`lteFadingChannel` is a closed-source toolbox call; `common.fading_taps` draws a static tap-delay line
+from the same public delay-profile table instead (documented deviation).  The (kk, jj) pairs are
+independent: `rank` / `world` deal them round-robin like `sweep.tiles_for_rank`, and the per-scenario sums
+returned under "_sums" add up across ranks (one all-reduce).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import common as c
+
+ESTIMATORS = ("LS", "MMSE", "MP", "OMP")
+
+
+def scenario_combs(N_carrier=1024, lo=4, hi=256):
+    """:13-17 -- the combs with distinct pilot counts floor(N_carrier/comb), first comb of each count."""
+    combs = np.arange(lo, hi + 1)
+    amounts = N_carrier // combs
+    _, ia = np.unique(amounts, return_index=True)                                   # first occurrence, like unique()
+    combs = combs[np.sort(ia)]
+    return combs, N_carrier // combs
+
+
+def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_SpF=7, Constellation="16QAM",
+        monteCarloRuns=100, SNR_dB=20, combs=None, DelayProfile="EPA", SamplingRate=4e7, seed=5, rank=0, world=1):
+    """T5/Task5_part2.m:4-320 with reg_pilot = 1 (:12)."""
+    lib = lib or c.default_lib()
+    T_Guard = Nfft // 8
+    N_symb = Amount_OFDM_Frames * Amount_ODFM_SpF
+    if combs is None:
+        combs, _ = scenario_combs(N_carrier)
+    combs = np.asarray(combs, dtype=int)
+    rng = np.random.Generator(np.random.PCG64(seed))                                # :23 rng(5)
+    channel_Seeds = rng.integers(1, 2 ** 16 + 1, size=(len(combs), monteCarloRuns))  # :24
+    dict_, bps = lib.constellation_func(Constellation)
+    amp_pilots = 2 * np.max(np.abs(dict_))                                          # :84-85
+    nmse_sum = np.zeros((4, len(combs)))
+    err_sum = np.zeros((4, len(combs)), dtype=np.int64)
+    bit_sum = np.zeros(len(combs), dtype=np.int64)
+    runs = np.zeros(len(combs), dtype=np.int64)
+    for kk, comb in enumerate(combs):                                               # :46
+        allCarriers, pilotCarriers, dataCarriers = c.layout_comb(Nfft, N_carrier, int(comb))    # :48-79
+        pilotValues = c.alternating_pilots(amp_pilots, len(pilotCarriers), N_symb)  # :86-91
+        Size_Buffer = N_symb * len(dataCarriers) * bps
+        input_bits = c.synthetic_bits(Size_Buffer, [seed, kk])                      # :96 (scrambler commented out, :99-115)
+        TX_IQ, pad = lib.mapping(input_bits, Constellation)                         # :119
+        X = lib.OFDM_map_carriers(TX_IQ, N_symb, Nfft, dataCarriers, pilotCarriers, pilotValues)   # :123
+        Tx = np.asarray(lib.OFDM_modulator(X, T_Guard)).ravel(order="F")            # :130-132
+        Tx_noised, _ = lib.Noise(SNR_dB, Tx, seed=seed, stream=kk)                  # :134 (noise BEFORE the channel)
+        K = int(np.ceil(Nfft / comb))                                               # :184
+        S = lib.sensing_matrix(pilotCarriers, Nfft, K)                              # :181-189 closed form
+        for jj in range(monteCarloRuns):                                            # :148
+            if (kk * monteCarloRuns + jj) % world != rank:
+                continue
+            taps = c.fading_taps(DelayProfile, SamplingRate, channel_Seeds[kk, jj])  # :150-152
+            h_t, H_f = lib.get_MP_channel_resp(taps, Nfft)                          # :154-155
+            rx = c.conv_truncate(lib, Tx_noised, h_t)
+            rx = rx.reshape((Nfft + T_Guard, N_symb), order="F")                    # :169
+            Xr = lib.OFDM_demodulator(rx, T_Guard)                                  # :172
+            h_full = np.zeros(N_carrier, dtype=np.complex128)
+            h_full[:min(len(h_t), N_carrier)] = np.asarray(h_t)[:N_carrier]         # :176 h_t(1:N_carrier).'
+            H = {"LS": lib.LS_CE(Xr, pilotValues, pilotCarriers, N_carrier),                         # :174
+                 "MMSE": lib.MMSE_CE(Xr, pilotValues, pilotCarriers, Nfft, N_carrier, h_full, SNR_dB)}   # :177
+            Y = np.asarray(lib.get_payload(np.asarray(Xr)[:, :1], pilotCarriers)).ravel() / pilotValues[:, 0]   # :190
+            n_paths = taps.shape[0]                                                 # length(info.PathSampleDelays)
+            H["MP"], _ = lib.MP_estimate(Y, S, Nfft, n_paths)                       # :192
+            H["OMP"], _, _ = lib.OMP_estimate(Y, S, Nfft, n_paths, SNR_dB)          # :193
+            for e, name in enumerate(ESTIMATORS):
+                nmse_sum[e, kk] += c.mse_row(H_f, H[name], N_carrier)               # :202-205
+                eq = lib.equalize_signal(Xr, H[name], N_carrier)                    # :269-272
+                RX_IQ = np.asarray(lib.get_payload(eq, dataCarriers)).ravel(order="F")   # :281-282
+                output_bits = lib.demapping(pad, RX_IQ, Constellation)              # :284
+                err_sum[e, kk] += lib.BER_func(input_bits, np.asarray(output_bits).ravel(), return_count=True)   # :286
+            bit_sum[kk] += input_bits.size
+            runs[kk] += 1
+    safe = np.maximum(runs, 1)
+    return {"driver": "Task 5/Task5_part2.m", "combs": combs, "amounts_pilots": N_carrier // combs,
+            "estimators": list(ESTIMATORS), "monteCarloRuns": monteCarloRuns, "SNR_dB": SNR_dB,
+            "NMSEs": nmse_sum / safe, "BERs": err_sum / np.maximum(bit_sum, 1),     # :309-318 (mean over jj)
+            "_sums": {"nmse": nmse_sum, "errors": err_sum, "bits": bit_sum, "runs": runs}}
+
+
+if __name__ == "__main__":
+    c.cli(run, __doc__)

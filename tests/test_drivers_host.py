@@ -1,0 +1,89 @@
+"""Driver replays (ofdm_course_amd.drivers) on the CPU oracle: the scripts' own checks -- exact loop-back
+(T1/Main_model.m:99, T2/Main_model_Task_2.m:141,:153, T3/Main_model_Task_3.m:177) and the BER < 0.2 gates
+(T4/Main_model_Task_4.m:367, T5/Main_model_Task_5.m:275) -- and the host bookkeeping (layouts, combs, seeds).
+No GPU: `lib` is the oracle adapter, which is how the GPU tests obtain their expected tables too."""
+import numpy as np
+import pytest
+
+from oracle_lib import OracleLib
+
+
+@pytest.fixture(scope="module")
+def olib(oracle):
+    return OracleLib(oracle)
+
+
+@pytest.fixture(scope="module")
+def drivers():
+    from ofdm_course_amd import drivers as d
+    return d
+
+
+def test_layout_rules(drivers, oracle):
+    c = drivers.common
+    _, p, d = c.layout_percent(1024, 400, 25, tail=2)                 # T1/Main_model.m:14-21
+    assert p[0] == 1 and p[-1] == 400 and len(p) + len(d) == 400
+    pp, dd = oracle.pilot_layout_percent(1024, 400, 25, 2)[:2] if hasattr(oracle, "pilot_layout_percent") else (p, d)
+    assert np.array_equal(np.asarray(pp, dtype=float), p)
+    _, p1, d1 = c.layout_comb(4096, 1024, 1)                          # T5/Main_model_Task_5.m:24-33: all carriers pilots
+    assert len(p1) == 1024 and len(d1) == 0
+    _, p4, d4 = c.layout_comb(4096, 1024, 4)
+    assert np.array_equal(p4, np.arange(1, 1025, 4)) and len(d4) == 768
+    combs, amounts = drivers.task5_part2.scenario_combs(1024)         # T5/Task5_part2.m:13-17
+    assert len(combs) == 57 and combs[0] == 4 and amounts[0] == 256 and amounts[-1] == 4
+    assert len(set(amounts.tolist())) == 57
+
+
+def test_fading_taps(drivers):
+    t = drivers.common.fading_taps("EPA", 4e7, 1234)
+    assert np.isclose(np.sum(np.abs(t[:, 1]) ** 2), 1.0)
+    assert np.all(np.diff(t[:, 0].real) > 0) and t[-1, 0].real == 16   # 410 ns at 40 MHz
+    t2 = drivers.common.fading_taps("EPA", 4e7, 1234)
+    assert np.array_equal(t, t2)
+
+
+def test_task1_loopback(drivers, olib):
+    r = drivers.task1.run(olib, Nfft=256, N_carrier=100, Amount_OFDM_Frames=2, Amount_ODFM_SpF=3)
+    assert r["passed"] and r["BER"] == 0.0
+
+
+def test_task2_loopback(drivers, olib):
+    r = drivers.task2.run(olib, Nfft=256, N_carrier=100, Amount_OFDM_Frames=2, Amount_ODFM_SpF=3)
+    assert r["passed"] and r["passed_scrambled"]
+    assert not np.array_equal(r["_sc_bits"], r["_input_bits"])
+
+
+def test_task3_sweep_shape(drivers, olib):
+    r = drivers.task3.run(olib, Nfft=256, N_carrier=100, Amount_OFDM_Frames=2, Amount_ODFM_SpF=3, mp_desync=0,
+                          SNRs=[0, 10, 30])
+    assert r["passed"]                                                 # clean channel: exact loop-back (:177)
+    B = r["sweep"]["BERs"]
+    assert B.shape == (4, 3)
+    assert np.all(B[:, 0] >= B[:, 2]) and B[0, 2] == 0.0               # BER falls with SNR; BPSK clean at 30 dB
+
+
+def test_task4_gate(drivers, olib):
+    r = drivers.task4.run(olib, Nfft=256, N_carrier=100, Amount_OFDM_Frames=2, Amount_ODFM_SpF=5, noise_desync=1,
+                          SNR_dB=30, mp_desync=1, channel_taps=[[0, 1.0], [2, 0.5], [5, 0.2]])
+    assert r["passed"] and r["BER"] < 0.01
+
+
+def test_task5_tables(drivers, olib):
+    r = drivers.task5.run(olib, Nfft=512, N_carrier=128, comb=1, SNRs=[0, 15, 30])
+    M = r["sweep"]["MSEs"]
+    assert M.shape == (4, 3) and np.all(M[:, 0] > M[:, 2])             # every estimator improves with SNR
+    r4 = drivers.task5.run(olib, Nfft=512, N_carrier=128, comb=4, SNR_dB=30, SNRs=[20])
+    assert r4["passed"]
+
+
+def test_task5_part2_sharding(drivers, olib):
+    kw = dict(Nfft=512, N_carrier=128, combs=[4, 8], monteCarloRuns=3, SamplingRate=2e7)
+    full = drivers.task5_part2.run(olib, **kw)
+    parts = [drivers.task5_part2.run(olib, rank=r, world=2, **kw) for r in range(2)]
+    for k in ("nmse", "errors", "bits", "runs"):
+        tot = parts[0]["_sums"][k] + parts[1]["_sums"][k]
+        if k == "nmse":
+            np.testing.assert_allclose(tot, full["_sums"][k], rtol=1e-12)
+        else:
+            assert np.array_equal(tot, full["_sums"][k])
+    assert full["BERs"].shape == (4, 2) and np.all(full["_sums"]["runs"] == 3)

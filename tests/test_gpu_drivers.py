@@ -1,0 +1,109 @@
+"""Driver replays on the HIP library against the same replay on the CPU oracle:
+identical seeds, identical call order, host arrays in float64 -> fp64 kernels.  Bits and integer outputs
+must be identical; tables (MER, MSE, NMSE, frequency offsets) agree to the fp64 tolerances of DESIGN.md 4."""
+import numpy as np
+import pytest
+
+from oracle_lib import OracleLib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def olib(oracle):
+    return OracleLib(oracle)
+
+
+@pytest.fixture(scope="module")
+def drivers(ofdm):
+    from ofdm_course_amd import drivers as d
+    return d
+
+
+def test_task1_reference_size(drivers, ofdm, olib):
+    g = drivers.task1.run(ofdm)                                        # Nfft 1024, 16QAM, 50 symbols (as committed)
+    o = drivers.task1.run(olib)
+    assert g["passed"] and o["passed"] and g["BER"] == 0.0
+    assert np.array_equal(g["_output_bits"], o["_output_bits"])
+    np.testing.assert_allclose(g["_RX_IQ"], o["_RX_IQ"], atol=1e-12)
+
+
+def test_task1_noisy(drivers, ofdm, olib):
+    g = drivers.task1.run(ofdm, SNR_dB=2, Constellation="QPSK")
+    o = drivers.task1.run(olib, SNR_dB=2, Constellation="QPSK")
+    assert np.array_equal(g["_output_bits"], o["_output_bits"]) and g["BER"] == o["BER"] > 0
+
+
+def test_task2(drivers, ofdm, olib):
+    g = drivers.task2.run(ofdm)
+    o = drivers.task2.run(olib)
+    assert g["passed"] and g["passed_scrambled"]
+    assert np.array_equal(g["_sc_bits"], o["_sc_bits"]) and np.array_equal(g["_dsc_bits"], o["_dsc_bits"])
+
+
+def test_task3_run_and_sweep(drivers, ofdm, olib):
+    kw = dict(noise_desync=1, SNRs=np.arange(0, 31, 3.0))
+    g = drivers.task3.run(ofdm, **kw)
+    o = drivers.task3.run(olib, **kw)
+    assert np.array_equal(g["_dsc_bits"], o["_dsc_bits"]) and g["BER"] == o["BER"]
+    assert abs(g["MER_dB"] - o["MER_dB"]) < 1e-8
+    assert np.array_equal(g["sweep"]["BERs"], o["sweep"]["BERs"])
+    assert g["sweep"]["BERs"][3, 0] > 0.05 and g["sweep"]["BERs"][0, -1] == 0.0
+
+
+def test_task3_sto_cfo_flags(drivers, ofdm, olib):
+    kw = dict(time_desync=1, freq_desync=1, mp_desync=0, SNRs=[20.0], Constellations=("QPSK",))
+    g = drivers.task3.run(ofdm, **kw)
+    o = drivers.task3.run(olib, **kw)
+    assert g["BER"] == o["BER"] and abs(g["MER_dB"] - o["MER_dB"]) < 1e-7
+
+
+@pytest.mark.parametrize("sub", [0, 3, 4])
+def test_task4_full_sync(drivers, ofdm, olib, sub):
+    kw = dict(noise_desync=1, time_desync=1, freq_desync=1, mp_desync=1, SNR_dB=28, seed=10 + sub)
+    g = drivers.task4.run(ofdm, **kw)
+    o = drivers.task4.run(olib, **kw)
+    assert g["Time_Delay"] == o["Time_Delay"] and g["Freq_Shift"] == o["Freq_Shift"]
+    assert g["TgPosition"] == o["TgPosition"] and g["acf_fallback"] == o["acf_fallback"]
+    assert abs(g["FreqOffset"] - o["FreqOffset"]) < 1e-9
+    if np.isfinite(o["e_IFO"]):
+        assert g["e_IFO"] == o["e_IFO"]
+        assert abs(g["BER"] - o["BER"]) <= 3 / g["_input_bits"].size
+        if np.isfinite(o["MER_dB"]):
+            assert abs(g["MER_dB"] - o["MER_dB"]) < 1e-6 * max(1.0, abs(o["MER_dB"]))
+    else:
+        assert not np.isfinite(g["e_IFO"])
+
+
+def test_task4_committed_flags(drivers, ofdm, olib):
+    g = drivers.task4.run(ofdm)                                        # all impairments off (:81-87)
+    assert g["passed"] and g["BER"] == 0.0
+
+
+def test_task5_estimator_tables(drivers, ofdm, olib):
+    kw = dict(SNRs=[0.0, 10.0, 20.0, 30.0])                            # Nfft 4096, N_carrier 1024, comb 1 (as committed)
+    g = drivers.task5.run(ofdm, **kw)
+    o = drivers.task5.run(olib, **kw)
+    assert np.array_equal(g["OMP_index"], o["OMP_index"])
+    for k in ("LS", "MMSE", "MP", "OMP"):
+        assert g["MSE"][k] == pytest.approx(o["MSE"][k], rel=1e-6), k
+    np.testing.assert_allclose(g["sweep"]["MSEs"], o["sweep"]["MSEs"], rtol=1e-6)
+    np.testing.assert_allclose(g["_H_est"], o["_H_est"], rtol=1e-10, atol=1e-10)   # spline extrapolates to ~1e8 beyond N_carrier
+
+
+def test_task5_comb4_payload(drivers, ofdm, olib):
+    kw = dict(Nfft=2048, N_carrier=512, comb=4, Constellation="64QAM", SNR_dB=26, SNRs=[20.0])
+    g = drivers.task5.run(ofdm, **kw)
+    o = drivers.task5.run(olib, **kw)
+    assert np.array_equal(g["_dsc_bits"], o["_dsc_bits"]) and g["BER"] == o["BER"]
+    assert abs(g["MER_dB"] - o["MER_dB"]) < 1e-7
+    np.testing.assert_allclose(g["sweep"]["MSEs"], o["sweep"]["MSEs"], rtol=1e-6)
+
+
+def test_task5_part2_subset(drivers, ofdm, olib):
+    kw = dict(combs=[4, 16, 64], monteCarloRuns=3)                     # Nfft 4096 / N_carrier 1024 / EPA @ 40 MHz
+    g = drivers.task5_part2.run(ofdm, **kw)
+    o = drivers.task5_part2.run(olib, **kw)
+    assert np.array_equal(g["_sums"]["errors"], o["_sums"]["errors"])
+    np.testing.assert_allclose(g["NMSEs"], o["NMSEs"], rtol=1e-6)
+    assert np.array_equal(g["amounts_pilots"], [256, 64, 16])
