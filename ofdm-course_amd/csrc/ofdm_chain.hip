@@ -331,6 +331,7 @@ struct FastPlanView {
   void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;
   int64_t* ws_frames;
   hipEvent_t* ev;
+  int comb_lg_up;
 };
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
 int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
@@ -341,6 +342,7 @@ struct ofdm_rx_plan {
   int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
   int frame_words;
   int pilots_in_band;
+  int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
   void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr;
   int64_t ws_frames = 0;
@@ -416,6 +418,19 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
     if (pilot_carriers[p] > n_carrier) pl->pilots_in_band = 0;
   }
   if (rc != OFDM_OK) { delete pl; return rc; }
+  // comb layout (T5/Main_model_Task_5.m:18-22: pilotCarriers = 1 : comb : N_carrier)?  Then S^H Y is an inverse
+  // transform of size Nfft/comb and the fast path needs no dictionary correlation.
+  if (n_pilots >= 2 && pc0[0] == 0) {
+    const int comb = pc0[1] - pc0[0];
+    bool is_comb = comb >= 1 && nfft % comb == 0;
+    for (int p = 0; p < n_pilots && is_comb; ++p) is_comb = pc0[p] == comb * p;
+    const int m = is_comb ? nfft / comb : 0;
+    if (is_comb && m <= 512 && 512 % m == 0 && n_pilots <= m) {
+      int lg = 0;
+      while ((m << lg) < 512) ++lg;
+      pl->comb_lg_up = lg;
+    }
+  }
   // conj(S) transposed: sct[p][k] = exp(+2 pi i pc0[p] k / nfft); Gram table g[d] = sum_p exp(-2 pi i pc0[p] d / nfft)
   const size_t cs = pl->f64 ? sizeof(c64) : sizeof(c32);
   std::vector<c64> sct((size_t)n_pilots * k_atoms), gram(k_atoms);
@@ -522,6 +537,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.ws_stash = &pl->ws_stash; pv.ws_ypil = &pl->ws_ypil; pv.ws_tapidx = &pl->ws_tapidx; pv.ws_tapx = &pl->ws_tapx;
     pv.ws_frames = &pl->ws_frames;
     pv.ev = pl->timing ? pl->ev : nullptr;
+    pv.comb_lg_up = pl->comb_lg_up;
     pl->last_fast = 1;
     OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
     return st.finish();

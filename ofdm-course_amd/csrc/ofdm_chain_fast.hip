@@ -16,210 +16,9 @@
 // workgroup barrier at all (a wavefront's LDS operations are processed in order).  Only the bins
 // k < N_carrier are ever needed, so the last pass computes 2 of its 8 outputs when N_carrier <= Nfft/4.
 // Global loads are 16 bytes per lane (NW = 4), twiddles live in registers for the whole launch.
-#include <cstdlib>
-#include <type_traits>
-
-#include "demap_core.hpp"
-#include "fft_core.hpp"
+#include "chain_fast_core.hpp"
 
 namespace ofdm {
-
-constexpr int FAST_MAXT = 32;
-
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__host__ __device__ constexpr int wpad(int i) { return i + (i >> 3); }
-constexpr int WAVE_LDS_ELEMS = 512 + 64;
-
-// Twiddles of the two inner passes of the wave-local 512-point transform, kept in LDS as
-// [pass][t-1][lane] (lane-contiguous: conflict-free ds_read_b64, no VALU, no live registers):
-//   pass B: W_64^(t*(lane&7))      pass C: W_512^(t*lane)        t = 1..7
-// 2 * 7 * 64 complex values, shared by every wavefront of the workgroup.
-constexpr int WAVE_TW_ELEMS = 2 * 7 * 64;
-
-// tw = exp(-2 pi i m / N) table of the full transform, N = 512 * NW.  Call with all threads; the
-// caller synchronises the workgroup before the first transform.
-template <typename T, int NW>
-__device__ __forceinline__ void wave_tw_fill(cx<T>* __restrict__ twl, const cx<T>* __restrict__ tw) {
-  for (int i = threadIdx.x; i < WAVE_TW_ELEMS; i += 64 * NW) {
-    const int pass = i / 448, r = i - pass * 448, t = r / 64 + 1, l = r & 63;
-    twl[i] = pass == 0 ? tw[(t * (l & 7) * 8) * NW] : tw[(t * l) * NW];
-  }
-}
-
-// X0 and X1 of an 8-point DFT (forward): v0 <- sum v_t ; v1 <- sum v_t W8^t
-template <typename T>
-__device__ __forceinline__ void dft8_first2(cx<T> (&v)[8]) {
-  const T h = T(0.70710678118654752440084436210485);
-  const cx<T> a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
-  const cx<T> b0 = v[0] - v[4];
-  cx<T> b1 = v[1] - v[5], b2 = v[2] - v[6], b3 = v[3] - v[7];
-  b1 = mk<T>((b1.x + b1.y) * h, (b1.y - b1.x) * h);
-  b2 = mk<T>(b2.y, -b2.x);
-  b3 = mk<T>((b3.y - b3.x) * h, (-b3.x - b3.y) * h);
-  v[0] = (a0 + a2) + (a1 + a3);
-  v[1] = (b0 + b2) + (b1 + b3);
-}
-
-// Eight ds_read_b64 at base + e*STRIDE elements, issued back to back and waited for once.
-// Hand-issued because the compiler fuses neighbouring b64 reads into ds_read2_b64 / ds_read2st64_b64,
-// which move half the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table: 128 vs 256 B/clk).
-// One asm statement: the outputs only become valid at its trailing s_waitcnt.
-template <int STRIDE, bool ASM>
-__device__ __forceinline__ void lds_read8(cx<float> (&v)[8], const cx<float>* base) {
-  if constexpr (ASM) {
-    const unsigned a = (unsigned)(uintptr_t)base;            // LDS aperture: low 32 bits = LDS byte address
-    unsigned long long r0, r1, r2, r3, r4, r5, r6, r7;
-    asm volatile(
-        "ds_read_b64 %0, %8 offset:%9\n\t"
-        "ds_read_b64 %1, %8 offset:%10\n\t"
-        "ds_read_b64 %2, %8 offset:%11\n\t"
-        "ds_read_b64 %3, %8 offset:%12\n\t"
-        "ds_read_b64 %4, %8 offset:%13\n\t"
-        "ds_read_b64 %5, %8 offset:%14\n\t"
-        "ds_read_b64 %6, %8 offset:%15\n\t"
-        "ds_read_b64 %7, %8 offset:%16\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-        : "v"(a), "n"(0 * STRIDE * 8), "n"(1 * STRIDE * 8), "n"(2 * STRIDE * 8), "n"(3 * STRIDE * 8),
-          "n"(4 * STRIDE * 8), "n"(5 * STRIDE * 8), "n"(6 * STRIDE * 8), "n"(7 * STRIDE * 8)
-        : "memory");
-    const unsigned long long r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e].x = __uint_as_float((unsigned)r[e]);
-      v[e].y = __uint_as_float((unsigned)(r[e] >> 32));
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = base[STRIDE * e];
-  }
-}
-template <int STRIDE, bool ASM>
-__device__ __forceinline__ void lds_read8(cx<double> (&v)[8], const cx<double>* base) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = base[STRIDE * e];
-}
-
-// forward 512-point FFT inside one wavefront.  v[e] <-> y[lane + 64 e] on entry; on exit
-// v[t] = Y[lane + 64 t]  (t < 2 only when PRUNE2).  lw = this wavefront's private LDS region.
-// Padded addressing wpad(i) = i + i/8, written as one base per access pattern + immediates:
-//   scatter A : wpad(8 lane + t)            = 9 lane + t
-//   gather    : wpad(lane + 64 e)           = lane + lane/8 + 72 e
-//   scatter B : wpad(64 (lane/8) + lane%8 + 8 t) = 72 (lane/8) + lane%8 + 9 t
-template <typename T, bool PRUNE2, bool TWB_REG = true, bool ASMRD = false>
-__device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T> (&twb)[7],
-                                            const cx<T>* __restrict__ twl, cx<T>* __restrict__ lw) {
-  cx<T>* const sa = lw + 9 * lane;
-  cx<T>* const ga = lw + lane + (lane >> 3);
-  cx<T>* const sb = lw + 72 * (lane >> 3) + (lane & 7);
-  dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) sa[t] = v[t];
-  wave_sync();
-  lds_read8<72, ASMRD>(v, ga);
-  wave_sync();
-#pragma unroll
-  for (int t = 1; t < 8; ++t) v[t] = v[t] * (TWB_REG ? twb[t - 1] : twl[(t - 1) * 64 + lane]);
-  dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) sb[9 * t] = v[t];
-  wave_sync();
-  lds_read8<72, ASMRD>(v, ga);
-  wave_sync();
-#pragma unroll
-  for (int t = 1; t < 8; ++t) v[t] = v[t] * twl[448 + (t - 1) * 64 + lane];
-  if constexpr (PRUNE2) dft8_first2<T>(v);
-  else dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-}
-
-// ---- radix-NW decimation-in-frequency front end -------------------------------------------------
-// Thread gid (= 64*wave + lane) owns the butterflies m = gid*BPT + b, b < BPT = 8/NW.  Slot e = b*NW + t
-// holds x[m + 512 t].  After the stage slot b*NW + s holds y_s[m] = (sum_t x[m+512t] W_NW^(ts)) W_N^(m s).
-template <typename T, int NW>
-struct DifTw {
-  cx<T> w[NW > 1 ? (8 / NW) * (NW - 1) : 1];
-};
-
-template <typename T, int NW>
-__device__ __forceinline__ void dif_tw_init(DifTw<T, NW>& d, int gid, const cx<T>* __restrict__ tw) {
-  if constexpr (NW > 1) {
-    constexpr int BPT = 8 / NW;
-#pragma unroll
-    for (int b = 0; b < BPT; ++b)
-#pragma unroll
-      for (int s = 1; s < NW; ++s) d.w[b * (NW - 1) + (s - 1)] = tw[(gid * BPT + b) * s];
-  }
-}
-
-template <typename T, int NW>
-__device__ __forceinline__ void frame_load(cx<T> (&v)[8], const cx<T>* __restrict__ src /* first useful sample */,
-                                           int gid, int lane) {
-  if constexpr (NW == 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[lane + 64 * e];
-  } else {
-    constexpr int BPT = 8 / NW;
-#pragma unroll
-    for (int t = 0; t < NW; ++t)
-#pragma unroll
-      for (int b = 0; b < BPT; ++b) v[b * NW + t] = src[gid * BPT + b + 512 * t];
-  }
-}
-
-template <typename T, int NW>
-__device__ __forceinline__ void dif_stage(cx<T> (&v)[8], const DifTw<T, NW>& d) {
-  if constexpr (NW > 1) {
-    constexpr int BPT = 8 / NW;
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) {
-      if constexpr (NW == 2) dft2<T, false>(v[b * 2], v[b * 2 + 1]);
-      else if constexpr (NW == 4) dft4<T, false>(v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]);
-      else dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-#pragma unroll
-      for (int s = 1; s < NW; ++s) v[b * NW + s] = v[b * NW + s] * d.w[b * (NW - 1) + (s - 1)];
-    }
-  }
-}
-
-// exchange: y_s[m] -> ex[s*576 + m]; then wavefront s gathers y_s[lane + 64 e].  Region s of the exchange
-// buffer doubles as wavefront s's private scratch for its 512-point transform: the barrier in front of
-// the next scatter is only reached by a wavefront that has finished its transform.
-template <typename T, int NW>
-__device__ __forceinline__ void dif_scatter(const cx<T> (&v)[8], int gid, cx<T>* __restrict__ ex) {
-  constexpr int BPT = 8 / NW;
-#pragma unroll
-  for (int s = 0; s < NW; ++s)
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) ex[s * WAVE_LDS_ELEMS + gid * BPT + b] = v[b * NW + s];
-}
-template <typename T, bool ASMRD = false>
-__device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, const cx<T>* __restrict__ ex) {
-  lds_read8<64, ASMRD>(v, ex + wave * WAVE_LDS_ELEMS + lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// parameters shared by the three kernels
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-struct FastParams {
-  int n_symb, t_guard, n_carrier, np, nd, k_atoms, taps, frame_words, bps;
-  const int16_t* prole;      // [nfft] pilot position of a carrier or -1
-  const int16_t* drole;      // [nfft] data position of a carrier or -1
-  const cx<T>* pilots;       // [np]
-  const cx<T>* sct;          // [np][k_atoms] conj(S), atom index fastest
-  const c64* gram;           // [k_atoms]
-  const cx<T>* tw;           // [nfft]
-  // workspace
-  cx<T>* stash;              // [n_frames][n_carrier]  X(1..N_carrier, 1)
-  cx<T>* ypil;               // [n_frames][np]
-  int32_t* tap_idx;          // [n_frames][taps]   0-based atom index, -1 = unused
-  c64* tap_x;                // [n_frames][taps]
-};
 
 // ---------------------------------------------------------------------------------------------
 // kernel 1: symbol 1 -> stash + Y
@@ -406,113 +205,8 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
   if (sl == 0) { ctl[0] = 0; ctl[1] = live ? 0 : 1; ((double*)(ctl + 2))[0] = ynorm; }
   wave_sync();
   const T g0 = gl[0].x;
-  constexpr int RT = 8;
-  if (taps <= RT) {
-    // ---- register-resident OMP (dominant_taps <= 8): the iteration loop is fully unrolled, so the number
-    // of picks made so far is the compile-time constant `it` and every index into L / z / x / pk is
-    // static.  All lanes of a frame's group compute the tiny solve redundantly from group-uniform
-    // inputs: no serial lane, no LDS state, no broadcast.  L is the lower Cholesky factor of the Gram
-    // of the picked atoms with 1/L[j][j] on the diagonal (tri(i,j) = i(i+1)/2 + j).
-    int pk[RT];
-    cx<T> xr[RT], zr[RT], Lr[RT * (RT + 1) / 2];
-    T Ld[RT];                                      // 1 / L[j][j]
-#pragma unroll
-    for (int i = 0; i < RT; ++i) { pk[i] = -1; xr[i] = zr[i] = mk<T>(0, 0); Ld[i] = T(0); }
-    bool active = live;
-    int n = 0;
-    double rho = ynorm;
-#pragma unroll
-    for (int it = 0; it < RT; ++it) {
-      if (it >= taps) break;
-      // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
-      float bs = -1.0f;
-      int bi = 0x7fffffff;
-      for (int k = sl; k < K; k += LPF) {
-        cx<T> c = cf[k];
-#pragma unroll
-        for (int qq = 0; qq < it; ++qq) {
-          const int d = pk[qq] - k;
-          const cx<T> gv = gl[d >= 0 ? d : -d];
-          c = c - (d >= 0 ? gv : conj(gv)) * xr[qq];
-        }
-        const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
-        if (sc > bs) { bs = sc; bi = k; }          // ascending k inside a lane: strict > keeps the first
-      }
-      for (int off = LPF >> 1; off > 0; off >>= 1) {
-        const float os = __shfl_xor(bs, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-      }
-      const int kp = bi < K ? bi : 0;              // all-NaN scores: MATLAB max returns index 1
-      if (active) {
-        int dup = -1;
-#pragma unroll
-        for (int qq = 0; qq < it; ++qq) if (pk[qq] == kp) dup = qq;
-        if (dup >= 0) {
-          // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
-          cx<T> half = mk<T>(0, 0);
-#pragma unroll
-          for (int qq = 0; qq < it; ++qq) if (qq == dup) { xr[qq] = xr[qq] * (T)0.5; half = xr[qq]; }
-          xr[it] = half;
-          pk[it] = kp;
-          n = it + 1;
-          active = false;
-        } else {
-          pk[it] = kp;
-          // new Cholesky row: G[it][j] = a_it^H a_j = gram[idx_j - idx_it]
-          T dd = g0;
-#pragma unroll
-          for (int jq = 0; jq < it; ++jq) {
-            const int d = pk[jq] - kp;
-            cx<T> sgm = d >= 0 ? gl[d] : conj(gl[-d]);
-#pragma unroll
-            for (int k2 = 0; k2 < jq; ++k2) sgm = sgm - mulc(Lr[it * (it + 1) / 2 + k2], Lr[jq * (jq + 1) / 2 + k2]);
-            const cx<T> l = sgm * Ld[jq];
-            Lr[it * (it + 1) / 2 + jq] = l;
-            dd -= norm2(l);
-          }
-          const T inv_lnn = T(1) / sqrt(dd);
-          Ld[it] = inv_lnn;
-          // forward substitution (only the new entry changes): b_it = a_it^H y = c0[kp]
-          cx<T> sz = cf[kp];
-#pragma unroll
-          for (int k2 = 0; k2 < it; ++k2) sz = sz - Lr[it * (it + 1) / 2 + k2] * zr[k2];
-          const cx<T> zn = sz * inv_lnn;
-          zr[it] = zn;
-          // back substitution L^H x = z
-#pragma unroll
-          for (int r = it; r >= 0; --r) {
-            cx<T> acc = zr[r];
-#pragma unroll
-            for (int k2 = r + 1; k2 <= it; ++k2) acc = acc - mulc(xr[k2], Lr[k2 * (k2 + 1) / 2 + r]);
-            xr[r] = acc * Ld[r];
-          }
-          // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
-          const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
-          if (it >= 1 && (!(num > 0.0) || sqrt(num / rho) < 1e-2)) active = false;
-          rho -= num;
-          n = it + 1;
-        }
-      }
-    }
-    // est_fade_chan(index(i1)) = x(i1): a later duplicate overwrites an earlier one (:31-33)
-    if (live && sl == 0) {
-#pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        if (t < taps) {
-          int idx = -1;
-          c64 xo{0, 0};
-          if (t < n) {
-            idx = pk[t];
-            xo = c64{(double)xr[t].x, (double)xr[t].y};
-#pragma unroll
-            for (int q2 = t + 1; q2 < RT; ++q2) if (q2 < n && pk[q2] == idx) xo = c64{0, 0};
-          }
-          P.tap_idx[f * taps + t] = idx;
-          P.tap_x[f * taps + t] = xo;
-        }
-      }
-    }
+  if (taps <= OMP_RT) {
+    omp_frame_reg<T>(P, cf, gl, K, taps, LPF, sl, live, ynorm, f);
     return;
   }
   // ---- generic path (more than 8 taps): per-frame state in LDS, serial solve on the group's first lane
@@ -752,6 +446,7 @@ struct FastPlanView {
   void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;   // workspace owned by the plan
   int64_t* ws_frames;
   hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
+  int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
 };
 
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
@@ -790,30 +485,37 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   const int ncu = ctx().num_cu;
   hipStream_t st = ctx().stream;
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
-  // kernel 1
-  {
-    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * std::max(1, 16 / NW));
-    hipLaunchKernelGGL((rx_pilot_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), 0, st, P, (const cx<T>*)rx, n_frames);
-    OFDM_TRY(check_launch("rx_pilot_kernel"));
-  }
-  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
-  // kernel 2
-  {
-    const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
-    OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
-    const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
-    const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) && lay.fpw >= 2 &&
-                      !getenv("OFDM_OMP_NO_MFMA");
-    if (mfma) {
-      if constexpr (std::is_same<T, float>::value) {
-        OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-        hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
-      }
-    } else {
-      OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-      hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+  const bool fused = pv.comb_lg_up >= 0 && pv.taps <= OMP_RT && pv.k_atoms <= 512 && !getenv("OFDM_FAST_UNFUSED");
+  if (fused) {
+    // kernels 1+2 in one launch (comb pilots): c0 by a wave-local inverse transform (ofdm_chain_pilot.hip)
+    OFDM_TRY(pilot_omp_run<T>(P, 512 * NW, PRUNE2, pv.comb_lg_up, rx, n_frames));
+    if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
+  } else {
+    // kernel 1
+    {
+      const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * std::max(1, 16 / NW));
+      hipLaunchKernelGGL((rx_pilot_kernel<T, NW, PRUNE2>), dim3(grid), dim3(64 * NW), 0, st, P, (const cx<T>*)rx, n_frames);
+      OFDM_TRY(check_launch("rx_pilot_kernel"));
     }
-    OFDM_TRY(check_launch("omp_batch_kernel"));
+    if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
+    // kernel 2
+    {
+      const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
+      OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
+      const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
+      const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) && lay.fpw >= 2 &&
+                        !getenv("OFDM_OMP_NO_MFMA");
+      if (mfma) {
+        if constexpr (std::is_same<T, float>::value) {
+          OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+          hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+        }
+      } else {
+        OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+        hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+      }
+      OFDM_TRY(check_launch("omp_batch_kernel"));
+    }
   }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
   // kernel 3
@@ -824,15 +526,9 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     OFDM_ARG(dyn <= 150 * 1024, "rx_chain_task5: symbol stage needs %zu bytes of LDS", dyn);
     // persistent grid = CUs x resident workgroups per CU (from the occupancy API: registers + LDS);
     // workgroups are independent, so an optimistic answer only queues a few of them.
-    auto blocks_per_cu = [&](auto kern) -> int {
-      int nb = 0;
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, dyn) != hipSuccess || nb < 1) nb = 1;
-      if (const char* e = getenv("OFDM_FAST_WG_PER_CU")) nb = std::max(1, atoi(e));
-      return std::min(nb, 8);
-    };
     auto launch = [&](auto kern) -> int {
-      static const int per_cu = blocks_per_cu(kern);       // per instantiation
+      int per_cu = resident_blocks_per_cu((const void*)kern, 64 * NW, dyn);
+      if (const char* e = getenv("OFDM_FAST_WG_PER_CU")) per_cu = std::max(1, atoi(e));
       const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ncu * per_cu);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), dyn, st, P, (const cx<T>*)rx, n_frames, (uint32_t*)bits,
                          (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
