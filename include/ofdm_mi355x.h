@@ -187,7 +187,8 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
 /* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
  * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call
- * (the generic single-kernel path reports {0, 0, total}). */
+ * (comb pilot layouts run the first two as one launch and report {symbol-1 + OMP kernel, 0, symbols
+ * kernel}; the generic single-kernel path reports {0, 0, total}). */
 int ofdm_rx_plan_set_timing(ofdm_rx_plan* plan, int enable);
 int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* plan, float* ms3);
 int ofdm_rx_chain_task5(ofdm_rx_plan* plan, const void* rx, int64_t n_frames,

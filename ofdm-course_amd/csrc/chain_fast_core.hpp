@@ -19,7 +19,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__host__ __device__ constexpr int wpad(int i) { return i + (i >> 3); }
 constexpr int WAVE_LDS_ELEMS = 512 + 64;
 
 // Twiddles of the two inner passes of the wave-local 512-point transform, kept in LDS as
@@ -94,27 +93,32 @@ __device__ __forceinline__ void lds_read8(cx<double> (&v)[8], const cx<double>* 
 
 // forward 512-point FFT inside one wavefront.  v[e] <-> y[lane + 64 e] on entry; on exit
 // v[t] = Y[lane + 64 t]  (t < 2 only when PRUNE2).  lw = this wavefront's private LDS region.
-// Padded addressing wpad(i) = i + i/8, written as one base per access pattern + immediates:
-//   scatter A : wpad(8 lane + t)            = 9 lane + t
-//   gather    : wpad(lane + 64 e)           = lane + lane/8 + 72 e
-//   scatter B : wpad(64 (lane/8) + lane%8 + 8 t) = 72 (lane/8) + lane%8 + 9 t
+// Two transposes through LDS, each laid out as a separable sum so that every access is one base register
+// plus an immediate, and every ds_read_b64 / ds_write_b64 of a half-wave (32 lanes x 8 bytes = all 64 banks)
+// hits 32 distinct bank pairs (checked exhaustively; the earlier i + i/8 padding left a 2-way conflict on
+// three lanes of every gather):
+//   T1 (k1 <-> n_mid):  j = 66 n_mid + 8 n_lo + n_lo/4 + k1     scatter lane = 8 n_mid + n_lo, t = k1
+//                                                               gather  lane = 8 n_lo + k1,    e = n_mid
+//   T2 (k2 <-> n_lo):   j = 72 n_lo + 8 k2 + k2/4 + k1          scatter lane = 8 n_lo + k1,    t = k2
+//                                                               gather  lane = k1 + 8 k2,      e = n_lo
+// Both gathers share the base lane + lane/32.  Largest index 568 < WAVE_LDS_ELEMS.
 template <typename T, bool PRUNE2, bool TWB_REG = true, bool ASMRD = false>
 __device__ __forceinline__ void wave_fft512(cx<T> (&v)[8], int lane, const cx<T> (&twb)[7],
                                             const cx<T>* __restrict__ twl, cx<T>* __restrict__ lw) {
-  cx<T>* const sa = lw + 9 * lane;
-  cx<T>* const ga = lw + lane + (lane >> 3);
+  cx<T>* const sa = lw + 66 * (lane >> 3) + 8 * (lane & 7) + ((lane & 7) >> 2);
+  cx<T>* const ga = lw + lane + (lane >> 5);
   cx<T>* const sb = lw + 72 * (lane >> 3) + (lane & 7);
   dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
   for (int t = 0; t < 8; ++t) sa[t] = v[t];
   wave_sync();
-  lds_read8<72, ASMRD>(v, ga);
+  lds_read8<66, ASMRD>(v, ga);
   wave_sync();
 #pragma unroll
   for (int t = 1; t < 8; ++t) v[t] = v[t] * (TWB_REG ? twb[t - 1] : twl[(t - 1) * 64 + lane]);
   dft8<T, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) sb[9 * t] = v[t];
+  for (int t = 0; t < 8; ++t) sb[8 * t + (t >> 2)] = v[t];
   wave_sync();
   lds_read8<72, ASMRD>(v, ga);
   wave_sync();

@@ -332,6 +332,7 @@ struct FastPlanView {
   int64_t* ws_frames;
   hipEvent_t* ev;
   int comb_lg_up;
+  int* fused_out;
 };
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
 int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
@@ -349,6 +350,7 @@ struct ofdm_rx_plan {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int timing = 0;          // ofdm_rx_plan_set_timing
   int last_fast = 0;
+  int last_fused = 0;      // fast path ran rx_pilot_omp_kernel instead of rx_pilot_kernel + omp_batch_kernel
   ConstellationInfo cinfo;
   std::vector<c64> dict;
 };
@@ -495,7 +497,12 @@ int ofdm_rx_plan_set_timing(ofdm_rx_plan* pl, int enable) {
 int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* pl, float* ms3) {
   OFDM_ARG(pl && ms3 && pl->timing && pl->ev[0], "rx_plan_last_kernel_ms: timing is not enabled");
   OFDM_HIP(hipEventSynchronize(pl->ev[3]));
-  if (pl->last_fast) {
+  if (pl->last_fast && pl->last_fused) {
+    // rx_pilot_omp_kernel | (no separate OMP launch) | rx_symbols_kernel
+    OFDM_HIP(hipEventElapsedTime(&ms3[0], pl->ev[0], pl->ev[1]));
+    ms3[1] = 0.f;
+    OFDM_HIP(hipEventElapsedTime(&ms3[2], pl->ev[1], pl->ev[3]));
+  } else if (pl->last_fast) {
     for (int i = 0; i < 3; ++i) OFDM_HIP(hipEventElapsedTime(&ms3[i], pl->ev[i], pl->ev[i + 1]));
   } else {
     ms3[0] = ms3[1] = 0.f;
@@ -538,6 +545,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.ws_frames = &pl->ws_frames;
     pv.ev = pl->timing ? pl->ev : nullptr;
     pv.comb_lg_up = pl->comb_lg_up;
+    pv.fused_out = &pl->last_fused;
     pl->last_fast = 1;
     OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
     return st.finish();

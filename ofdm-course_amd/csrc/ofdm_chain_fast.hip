@@ -447,6 +447,7 @@ struct FastPlanView {
   int64_t* ws_frames;
   hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
   int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
+  int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
 };
 
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
@@ -486,6 +487,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   hipStream_t st = ctx().stream;
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
   const bool fused = pv.comb_lg_up >= 0 && pv.taps <= OMP_RT && pv.k_atoms <= 512 && !getenv("OFDM_FAST_UNFUSED");
+  if (pv.fused_out) *pv.fused_out = fused ? 1 : 0;
   if (fused) {
     // kernels 1+2 in one launch (comb pilots): c0 by a wave-local inverse transform (ofdm_chain_pilot.hip)
     OFDM_TRY(pilot_omp_run<T>(P, 512 * NW, PRUNE2, pv.comb_lg_up, rx, n_frames));
@@ -517,7 +519,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
       OFDM_TRY(check_launch("omp_batch_kernel"));
     }
   }
-  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
+  if (pv.ev && !fused) OFDM_HIP(hipEventRecord(pv.ev[2], st));
   // kernel 3
   {
     constexpr int N = 512 * NW;

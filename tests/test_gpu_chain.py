@@ -20,19 +20,27 @@ def _run(ofdm, oracle, cfg, n_frames, precision, seed=1):
     return data, out, ref, got_bits
 
 
-@pytest.mark.parametrize("path", ["fast", "generic"])
+@pytest.mark.parametrize("path", ["fast", "fast_unfused", "generic"])
 @pytest.mark.parametrize("precision", ["fp64", "fp32"])
 @pytest.mark.parametrize("nfft,nc,const", [(64, 32, "QPSK"), (256, 64, "16QAM"), (512, 100, "8PSK"),
                                             (1024, 256, "64QAM"), (1024, 400, "16QAM"), (2048, 512, "64QAM"),
                                             (4096, 1024, "256QAM")])
 def test_chain_matches_oracle(ofdm, oracle, monkeypatch, path, precision, nfft, nc, const):
-    """`fast` = 3-kernel pipeline (wave-local FFT + MFMA correlation) where supported (Nfft 512..4096),
-    `generic` = single fused kernel (every Nfft).  Both must reproduce the oracle."""
+    """`fast` = wave-local FFT pipeline where supported (Nfft 512..4096): comb pilots whose Nfft/comb divides 512
+    run symbol 1 + OMP as one launch with c0 from an inverse transform, `fast_unfused` forces the three-launch
+    form (MFMA dictionary correlation) that other layouts use; `generic` = single fused kernel (every Nfft).
+    All must reproduce the oracle."""
     from ofdm_course_amd import frames as fr
     if path == "generic":
         monkeypatch.setenv("OFDM_CHAIN_GENERIC", "1")
     else:
         monkeypatch.delenv("OFDM_CHAIN_GENERIC", raising=False)
+    if path == "fast_unfused":
+        if nfft < 512:
+            pytest.skip("fast path starts at Nfft = 512")
+        monkeypatch.setenv("OFDM_FAST_UNFUSED", "1")
+    else:
+        monkeypatch.delenv("OFDM_FAST_UNFUSED", raising=False)
     cfg = fr.config_small(nfft=nfft, n_carrier=nc, comb=4, const=const, n_symb=4 if nfft < 2048 else 14,
                           dominant_taps=3)
     if nfft == 2048:
@@ -120,6 +128,34 @@ def test_chain_config_c5_shape(ofdm, oracle):
     with pytest.raises(ofdm.OfdmError):
         fr.make_plan(cfg, ofdm, precision="fp64") and ofdm.rx_chain_task5(
             fr.make_plan(cfg, ofdm, precision="fp64"), np.asarray(data["rx"]).astype(np.complex128))
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+@pytest.mark.parametrize("nfft,nc,comb,taps_n,fpw", [(512, 128, 2, 1, 4), (512, 200, 8, 2, 1), (1024, 256, 2, 5, 2),
+                                                      (2048, 512, 8, 8, 4), (2048, 384, 16, 4, 8), (4096, 512, 8, 6, 4)])
+def test_chain_comb_pilot_stage(ofdm, oracle, monkeypatch, precision, nfft, nc, comb, taps_n, fpw):
+    """rx_pilot_omp_kernel over its parameter space: up-sampling factors 512/(Nfft/comb) = 1, 2, 4, 8, every tap
+    bucket (2, 4, 6, 8 register-resident picks), 1..8 frames per wavefront, ragged last group (21 frames)."""
+    from ofdm_course_amd import frames as fr
+    monkeypatch.delenv("OFDM_CHAIN_GENERIC", raising=False)
+    monkeypatch.delenv("OFDM_FAST_UNFUSED", raising=False)
+    monkeypatch.setenv("OFDM_PILOT_FPW", str(fpw))
+    rng = np.random.default_rng(nfft + comb)
+    d = np.sort(rng.choice(min(nc // comb - 1, nfft // 8 - 1), taps_n, replace=False))
+    d[0] = 0
+    taps = np.stack([d.astype(float), np.linspace(1.0, 0.3, taps_n)], axis=1)
+    cfg = fr.FrameConfig("comb", nfft, nc, comb, "16QAM", N_symb=3, taps=taps, dominant_taps=taps_n, SNR_dB=25.0)
+    nfr = 21
+    data, out, ref, got_bits = _run(ofdm, oracle, cfg, nfr, precision, seed=4)
+    idx = np.asarray(out["index"]).T
+    for f in range(nfr):
+        want = list(ref["index"][f])
+        assert list(idx[f][: len(want)]) == want and not idx[f][len(want):].any()
+    assert rel_l2(np.asarray(out["H"]).T, ref["H"]) < (1e-9 if precision == "fp64" else 2e-4)
+    if precision == "fp64":
+        assert np.array_equal(np.asarray(out["errors"]).astype(np.int64), ref["errors"])
+    else:
+        assert np.max(np.abs(np.asarray(out["errors"]).astype(np.int64) - ref["errors"])) <= 2
 
 
 def test_chain_many_taps_fast_path(ofdm, oracle):
