@@ -1,0 +1,160 @@
+"""One parity test per BASELINE.json configuration, each through the
+C ABI against the CPU oracle on the same seeded inputs at an oracle-sized slice, plus size-independent
+properties at the configuration's full size where the oracle would be too slow."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from oracle_lib import OracleLib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def olib(oracle):
+    return OracleLib(oracle)
+
+
+def test_c1_task1_plumbing(ofdm, olib):
+    """configs[0]: Task 1 Main_model.m, Nfft=64, QPSK, AWGN, 1k symbols (200 frames x 5)."""
+    from ofdm_course_amd.drivers import task1
+    kw = dict(Nfft=64, N_carrier=24, Amount_OFDM_Frames=200, Amount_ODFM_SpF=5, Percent_pilot=25,
+              Constellation="QPSK", SNR_dB=6)
+    g, o = task1.run(ofdm, **kw), task1.run(olib, **kw)
+    assert g["amount_pilots"] == 7 and g["amount_data_carriers"] == 17
+    assert np.array_equal(g["_output_bits"], o["_output_bits"]) and g["BER"] == o["BER"] > 0
+    clean = task1.run(ofdm, **{**kw, "SNR_dB": None})
+    assert clean["passed"]                                                       # T1/Main_model.m:99
+
+
+def test_c2_batched_ifft_fft(ofdm, oracle):
+    """configs[1]: Nfft=1024, 16-QAM, AWGN, 100k-symbol batched IFFT/FFT + CP."""
+    import torch
+    from ofdm_course_amd.drivers import common as dc
+    Nfft, Tg, Nc, const = 1024, 128, 400, "16QAM"
+    _, pil, dat = dc.layout_percent(Nfft, Nc, 25, tail=2)
+    d, bps = ofdm.constellation_func(const)
+    amp = 2 * float(np.max(np.abs(d)))
+    # oracle-sized slice, fp64 host flavour: identical bits after mod -> Noise -> demod -> demap
+    ns = 500
+    bits = dc.synthetic_bits(ns * len(dat) * bps, 21)
+    iq, pad = ofdm.mapping(bits, const)
+    X = ofdm.OFDM_map_carriers(iq, ns, Nfft, dat, pil, amp)
+    tx = ofdm.OFDM_modulator(X, Tg)
+    rx, nvar = ofdm.Noise(9.0, np.asarray(tx).ravel(order="F"), seed=99)
+    Xr = ofdm.OFDM_demodulator(np.asarray(rx).reshape((Nfft + Tg, ns), order="F"), Tg)
+    got = np.asarray(ofdm.demapping(pad, np.asarray(ofdm.get_payload(Xr, dat)).ravel(order="F"), const))
+    oX = oracle.OFDM_map_carriers(oracle.mapping(bits, const)[0], ns, Nfft, dat, pil, amp)
+    otx = oracle.OFDM_modulator(oX, Tg)
+    assert rel_l2(np.asarray(tx), otx) < 1e-13 * 10
+    nr, ni = oracle.awgn_philox(otx.size, 99, 0)
+    orx, onvar = oracle.Noise(9.0, otx.ravel(order="F"), nr, ni)
+    oXr = oracle.OFDM_demodulator(orx.reshape((Nfft + Tg, ns), order="F"), Tg)
+    want = oracle.demapping(pad, oracle.get_payload(oXr, dat).ravel(order="F"), const)
+    assert abs(nvar - onvar) < 1e-12 * onvar
+    assert np.array_equal(got, np.asarray(want).ravel())
+    assert 0 < np.count_nonzero(got != bits) < 0.1 * bits.size
+    # full size, fp32 device flavour: CP is an exact copy, demod(mod(X)) == X, BER of the clean loop-back is 0
+    ns = 100_000
+    dev = torch.device("cuda:0")
+    tb = torch.from_numpy(dc.synthetic_bits(ns * len(dat) * bps, 22)).to(dev)
+    iq, pad = ofdm.mapping(tb, const, precision="fp32")
+    X = ofdm.OFDM_map_carriers(iq, ns, Nfft, dat, pil, amp)
+    tx = ofdm.OFDM_modulator(X, Tg)
+    assert torch.equal(torch.view_as_real(tx[:Tg]), torch.view_as_real(tx[Nfft:]))          # T5/OFDM_modulator.m:8-9
+    Xr = ofdm.OFDM_demodulator(tx, Tg)
+    err = (torch.linalg.vector_norm(Xr - X) / torch.linalg.vector_norm(X)).item()
+    assert err < 1e-6 * 10                                                                   # fp32: 1e-6 * log2(Nfft)
+    out = ofdm.demapping(pad, ofdm.get_payload(Xr, dat), const)
+    assert ofdm.BER_func(tb, out, return_count=True) == 0
+
+
+def test_c3_sync_chain(ofdm, olib):
+    """configs[2]: Nfft=2048, 64-QAM, multipath + STO/CFO, AutoCorr coarse sync + LS (spline) equalise.
+    Impairment draw on which the reference's coarse sync decodes at this size (most draws do not, in the
+    oracle as well: the IFO search of remove_IFO.m:5-8 picks up a leakage line)."""
+    from ofdm_course_amd.drivers import task4
+    kw = dict(Nfft=2048, N_carrier=800, Constellation="64QAM", noise_desync=1, time_desync=1, freq_desync=1,
+              mp_desync=1, SNR_dB=30, seed=2)
+    g, o = task4.run(ofdm, **kw), task4.run(olib, **kw)
+    assert g["TgPosition"] == o["TgPosition"] and g["e_IFO"] == o["e_IFO"] == 16.0
+    assert abs(g["FreqOffset"] - o["FreqOffset"]) < 1e-9
+    assert o["passed"] and g["passed"]
+    assert abs(g["BER"] - o["BER"]) <= 3 / g["_input_bits"].size
+    assert abs(g["MER_dB"] - o["MER_dB"]) < 1e-6
+    np.testing.assert_allclose(g["_H_est"][:800], o["_H_est"][:800], rtol=1e-9, atol=1e-9)
+
+
+def test_c4_mmse_chain(ofdm, oracle):
+    """configs[3]: Nfft=4096, 64-QAM, comb pilots, MMSE_CE (+ its spline interpolation) -> equalise -> BER,
+    frames of 14 symbols (a slice of the 1M-symbol Monte-Carlo: every frame is independent)."""
+    from ofdm_course_amd import frames as fr
+    cfg = fr.FrameConfig("C4", 4096, 1024, 4, "64QAM")
+    nfr = 3
+    data = fr.make_frames(cfg, ofdm, nfr, seed=4, precision="fp64")
+    pv = np.repeat(data["pilots"][:, None], cfg.N_symb, axis=1)
+    h, _ = ofdm.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+    hh = np.zeros(cfg.N_carrier, dtype=np.complex128)
+    hh[: len(h)] = h
+    tot_g = tot_o = 0
+    for f in range(nfr):
+        rx = np.asarray(data["rx"])[:, f].reshape((cfg.Nfft + cfg.T_guard, cfg.N_symb), order="F")
+        X = ofdm.OFDM_demodulator(rx, cfg.T_guard)
+        Hl = ofdm.LS_CE(X, pv, cfg.pilotCarriers, cfg.N_carrier)
+        Hm = ofdm.MMSE_CE(X, pv, cfg.pilotCarriers, cfg.Nfft, cfg.N_carrier, hh, cfg.SNR_dB)
+        eq = ofdm.equalize_signal(X, Hm, cfg.N_carrier)
+        bits = np.asarray(ofdm.demapping(0, np.asarray(ofdm.get_payload(eq, cfg.dataCarriers)).ravel(order="F"),
+                                         cfg.Constellation))
+        oX = oracle.OFDM_demodulator(rx, cfg.T_guard)
+        oHl = oracle.LS_CE(oX, pv, cfg.pilotCarriers, cfg.N_carrier)
+        oHm = oracle.MMSE_CE(oX, pv, cfg.pilotCarriers, cfg.Nfft, cfg.N_carrier, hh, cfg.SNR_dB)
+        oHm = oHm[0] if isinstance(oHm, tuple) else oHm
+        oeq = oracle.equalize_signal(oX, oHm, cfg.N_carrier)
+        obits = np.asarray(oracle.demapping(0, oracle.get_payload(oeq, cfg.dataCarriers).ravel(order="F"),
+                                            cfg.Constellation)).ravel()
+        assert rel_l2(np.asarray(Hl), oHl) < 1e-10 and rel_l2(np.asarray(Hm), oHm) < 1e-9
+        assert np.array_equal(bits, obits)
+        tot_g += np.count_nonzero(bits != data["bits"][f])
+        tot_o += np.count_nonzero(obits != data["bits"][f])
+    assert tot_g == tot_o and 0 < tot_g < 0.2 * data["bits"].size
+
+
+def test_c5_snr_sweep_tiles(ofdm, oracle):
+    """configs[4]: Nfft=8192, 256-QAM, sparse 32-tap channel, OMP, SNR sweep dealt as (snr, batch) tiles.
+    Tiles of two ranks reproduce the single-rank totals (the sum the RCCL all-reduce forms), and one tile is
+    checked against the oracle."""
+    from ofdm_course_amd import frames as fr
+    from ofdm_course_amd import sweep
+    cfg = fr.config_C5()
+    snrs = [6.0, 18.0, 30.0]
+    fpt = 2                                                      # frames per tile
+    plan = fr.make_plan(cfg, ofdm, precision="fp32")
+
+    def run_tiles(tiles):
+        errs = np.zeros(len(snrs), dtype=np.int64)
+        nbits = np.zeros(len(snrs), dtype=np.int64)
+        for (si, bi) in tiles:
+            cfg.SNR_dB = snrs[si]
+            seed, stream0 = sweep.tile_seed_stream(7, si, bi, fpt)
+            data = fr.make_frames(cfg, ofdm, fpt, seed=seed, precision="fp32", frame0=stream0)
+            out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"])
+            errs[si] += int(np.asarray(out["errors"]).sum())
+            nbits[si] += data["bits"].size
+        return errs, nbits
+
+    full = run_tiles(sweep.tiles_for_rank(len(snrs), 2, 0, 1))
+    parts = [run_tiles(sweep.tiles_for_rank(len(snrs), 2, r, 2)) for r in range(2)]
+    assert np.array_equal(parts[0][0] + parts[1][0], full[0]) and np.array_equal(parts[0][1] + parts[1][1], full[1])
+    ber = full[0] / full[1]
+    assert ber[0] > ber[2]                                       # BER falls along the sweep
+    # one tile against the oracle (fp32 kernel vs fp64 oracle: near-tied picks may differ, the BER may not)
+    cfg.SNR_dB = snrs[2]
+    seed, stream0 = sweep.tile_seed_stream(7, 2, 0, fpt)
+    data = fr.make_frames(cfg, ofdm, fpt, seed=seed, precision="fp32", frame0=stream0)
+    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True)
+    ref = oracle.rx_chain_task5(np.asarray(data["rx"]).astype(np.complex128), cfg.Nfft, cfg.T_guard, cfg.N_carrier,
+                                cfg.pilotCarriers, cfg.dataCarriers, data["pilots"], cfg.K, cfg.dominant_taps,
+                                cfg.Constellation, ref_bits=data["bits"])
+    assert rel_l2(np.asarray(out["H"]).T, ref["H"]) < 5e-3
+    ge, oe = np.asarray(out["errors"]).astype(np.int64).sum(), ref["errors"].sum()
+    assert abs(int(ge) - int(oe)) <= 0.02 * max(int(oe), 50)
