@@ -32,35 +32,39 @@ __global__ __launch_bounds__(64 * NW) void rx_pilot_omp_kernel(FastParams<T> P, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
   const int np = P.np, K = P.k_atoms;
   const int G = NW * fpw;
-  DifTw<T, NW> dt;
   wave_tw_fill<T, NW>(twl, P.tw);
-  dif_tw_init<T, NW>(dt, gid, P.tw);
   for (int i = gid; i < K; i += 64 * NW) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
-  cx<T> twb[7];
-#pragma unroll
-  for (int t = 1; t < 8; ++t) twb[t - 1] = P.tw[(t * (lane & 7) * 8) * NW];
   __syncthreads();
-  int kk[NOUT], pp[NOUT];
-#pragma unroll
-  for (int t = 0; t < NOUT; ++t) {
-    kk[t] = NW * (lane + 64 * t) + wave;
-    pp[t] = kk[t] < P.n_carrier ? (int)P.prole[kk[t]] : -1;
-  }
   const int64_t L = (int64_t)(N + P.t_guard) * P.n_symb;
   const int64_t n_groups = (n_frames + G - 1) / G;
   const int up_mask = (1 << lg_up) - 1;
   const int LPF = 64 / fpw, grp = lane / LPF, sl = lane - grp * LPF;
-  cx<T> v[8], nx[8];
-  if ((int64_t)blockIdx.x * G < n_frames) frame_load<T, NW>(nx, rx + (int64_t)blockIdx.x * G * L + P.t_guard, gid, lane);
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // Everything the transforms keep in registers (DIF / pass-B twiddles, carrier roles, the sample prefetch) is
+    // (re)built per group behind an opaque zero, so that none of it stays live across the register-hungry OMP
+    // phase below: 166 -> ~120 VGPRs, one more resident workgroup per CU.  The reloads hit L1 / L2.
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    DifTw<T, NW> dt;
+    dif_tw_init<T, NW>(dt, gid + opq, P.tw);
+    cx<T> twb[7];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) twb[t - 1] = P.tw[(t * ((lane + opq) & 7) * 8) * NW];
+    int kk[NOUT], pp[NOUT];
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) {
+      kk[t] = NW * (lane + 64 * t) + wave + opq;
+      pp[t] = kk[t] < P.n_carrier ? (int)P.prole[kk[t]] : -1;
+    }
+    cx<T> v[8], nx[8];
+    frame_load<T, NW>(nx, rx + g * G * L + P.t_guard, gid, lane);
     // ---- symbol 1 of the group's frames: FFT -> stash + Y (LDS)
     for (int j = 0; j < G; ++j) {
       const int64_t f = g * G + j;
       if (f >= n_frames) break;                                // workgroup-uniform
-      const int64_t fn = j + 1 < G ? f + 1 : (g + gridDim.x) * G;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = nx[e];
-      if (fn < n_frames) frame_load<T, NW>(nx, rx + fn * L + P.t_guard, gid, lane);
+      if (j + 1 < G && f + 1 < n_frames) frame_load<T, NW>(nx, rx + (f + 1) * L + P.t_guard, gid, lane);
       if constexpr (NW > 1) {
         dif_stage<T, NW>(v, dt);
         __syncthreads();
@@ -111,11 +115,11 @@ __global__ __launch_bounds__(64 * NW) void rx_pilot_omp_kernel(FastParams<T> P, 
 
 template <typename T, int NW, bool PRUNE2, int RT>
 static int pilot_omp_launch(const FastParams<T>& P, int lg_up, const void* rx, int64_t n_frames) {
-  // frames per wavefront: as many as keep the per-group Y / c0 buffer within ~16 KB (3-4 workgroups per CU)
+  // frames per wavefront: as many as keep the per-group Y / c0 buffer within 8 KB (4 workgroups of ~35 KB per CU)
   const int ystride = std::max(P.np, P.k_atoms);
   int fpw = 4;
   if (const char* e = getenv("OFDM_PILOT_FPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) fpw = v; }
-  while (fpw > 1 && sizeof(cx<T>) * (size_t)NW * fpw * ystride > 16 * 1024) fpw >>= 1;
+  while (fpw > 1 && sizeof(cx<T>) * (size_t)NW * fpw * ystride > 8 * 1024) fpw >>= 1;
   const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS + P.k_atoms + (size_t)NW * fpw * ystride);
   OFDM_ARG(dyn <= 150 * 1024, "rx_chain_task5: pilot stage needs %zu bytes of LDS", dyn);
   auto kern = rx_pilot_omp_kernel<T, NW, PRUNE2, RT>;
