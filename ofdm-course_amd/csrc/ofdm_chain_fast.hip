@@ -1,21 +1,26 @@
 // Fast path of the fused Task-5 RX chain for Nfft = 512 * NW (NW = 1, 2, 4, 8 wavefronts per frame),
-// i.e. the metric configuration Nfft = 2048 and its neighbours.  Three launches per batch:
+// i.e. the metric configuration Nfft = 2048 and its neighbours.  Two or three launches per batch:
 //
-//   rx_pilot_kernel    symbol 1 of every frame: FFT -> X1 stash (carriers 1..N_carrier) and
-//                      Y = X(pilotCarriers,1)./pilotValues(:,1)                     (Task5_part2.m:190)
-//   omp_batch_kernel   8 frames per workgroup: dictionary correlation c0 = S^H Y as ONE real GEMM on
-//                      the matrix cores (v_mfma_f32_16x16x4_f32, exact f32), then one wavefront per
-//                      frame runs the OMP iterations (OMP_estimate.m:7-23) in batch form
+//   rx_pilot_omp_kernel (ofdm_chain_pilot.hip; comb pilots whose Nfft/comb divides 512, <= 8 taps)
+//                      symbol 1 of every frame: FFT -> X1 stash + Y = X(pilotCarriers,1)./pilotValues(:,1)
+//                      (Task5_part2.m:190), c0 = S^H Y as one wave-local inverse transform, OMP iterations
+//   -- or, for any other pilot layout / tap count --
+//   rx_pilot_kernel    symbol 1 of every frame: FFT -> X1 stash and Y
+//   omp_batch_kernel   16 frames per workgroup: c0 = S^H Y as ONE real GEMM on the matrix cores
+//                      (v_mfma_f32_16x16x4_f32, exact f32), then 4 frames per wavefront run the OMP
+//                      iterations (OMP_estimate.m:7-23) side by side in batch form
+//   -- then --
 //   rx_symbols_kernel  per frame: H = fft(h) on carriers 1..N_carrier from the taps, then every symbol:
 //                      FFT -> equalize_signal -> get_payload -> demapping -> packed bits -> BER numerator
 //
-// FFT structure (CDNA4-specific): one frame = NW wavefronts.  A radix-NW decimation-in-frequency
-// stage (registers + one LDS exchange, two workgroup barriers) splits the transform into NW
-// independent 512-point transforms, and each of those is done by ONE wavefront: 64 lanes x 8 points in
-// registers, three radix-8 passes whose two transposes go through a wave-private LDS region with no
+// FFT structure (CDNA4-specific, chain_fast_core.hpp): one frame = NW wavefronts.  A radix-NW
+// decimation-in-frequency stage (registers + one LDS exchange, two workgroup barriers) splits the transform
+// into NW independent 512-point transforms, and each of those is done by ONE wavefront: 64 lanes x 8 points
+// in registers, three radix-8 passes whose two transposes go through a wave-private LDS region with no
 // workgroup barrier at all (a wavefront's LDS operations are processed in order).  Only the bins
 // k < N_carrier are ever needed, so the last pass computes 2 of its 8 outputs when N_carrier <= Nfft/4.
-// Global loads are 16 bytes per lane (NW = 4), twiddles live in registers for the whole launch.
+// Global loads are 16 bytes per lane (NW = 4); DIF and second-pass twiddles live in registers, third-pass
+// twiddles in an LDS table.
 #include "chain_fast_core.hpp"
 
 namespace ofdm {
