@@ -184,6 +184,15 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
  * errors_out[n_frames] uint32 bit errors per frame (may be NULL when ref_bits is NULL);
  * h_out (may be NULL): [n_carrier x n_frames] OMP estimate; index_out (may be NULL): [dominant_taps x n_frames]
  * 1-based picks, 0 = unused slot. */
+/* MMSE mode of a plan: ofdm_rx_chain_task5 then estimates the channel of every frame with
+ * MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR) (T5/MMSE_CE.m:1-39, as called per Monte-Carlo run at
+ * T5/Task5_part2.m:176-177) instead of OMP_estimate, and index_out is not written.  For a fixed (h, SNR) that
+ * estimator is one linear operator on the pilot LS values of symbol 1 (rms delay spread :19-24, Rpp :33-35, the
+ * mrdivide of :36 and the spline re-interpolation of :38 folded together); it is built here once, on the host in
+ * double, and applied to a whole batch as one complex GEMM (matrix cores in fp32).  h: host array of n_h complex
+ * values in the precision of `flags` (OFDM_F32 / OFDM_F64); h = NULL returns the plan to OMP mode.
+ * Needs 2..512 pilots; the chain call needs the fast-path geometry (Nfft 512..4096). */
+int ofdm_rx_plan_set_mmse(ofdm_rx_plan* plan, const void* h, int64_t n_h, double snr_db, int flags);
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
 /* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
  * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call

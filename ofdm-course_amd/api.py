@@ -606,6 +606,16 @@ class RxPlan:
         self.frame_bits = self.n_data * self.N_symb * self.bps
         self.frame_samples = (self.Nfft + self.T_guard) * self.N_symb
 
+    def set_mmse(self, h=None, SNR=0.0):
+        """Switch the plan's estimator to MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR) (T5/MMSE_CE.m:1-39) for
+        every frame of a batch; `h=None` returns to OMP_estimate.  h: the impulse response handed to MMSE_CE."""
+        if h is None:
+            L.check(self.lib.ofdm_rx_plan_set_mmse(self.handle, None, 0, 0.0, L.OFDM_F64), "rx_plan_set_mmse")
+            return
+        hh = np.ascontiguousarray(np.asarray(h.cpu().numpy() if _is_torch(h) else h).ravel().astype(np.complex128))
+        L.check(self.lib.ofdm_rx_plan_set_mmse(self.handle, hh.ctypes.data_as(C.c_void_p), hh.size, float(SNR),
+                                               L.OFDM_F64 | L.OFDM_HOST), "rx_plan_set_mmse")
+
     def set_timing(self, enable=True):
         L.check(self.lib.ofdm_rx_plan_set_timing(self.handle, int(bool(enable))), "rx_plan_set_timing")
 

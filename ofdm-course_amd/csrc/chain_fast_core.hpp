@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <map>
 #include <utility>
+#include <vector>
 #include <type_traits>
 
 #include "demap_core.hpp"
@@ -210,6 +211,7 @@ struct FastParams {
   cx<T>* ypil;               // [n_frames][np]
   int32_t* tap_idx;          // [n_frames][taps]   0-based atom index, -1 = unused
   c64* tap_x;                // [n_frames][taps]
+  const cx<T>* h_in;         // [n_frames][n_carrier] channel estimate made by another stage (MMSE mode), or nullptr
 };
 
 
@@ -372,6 +374,12 @@ inline int resident_blocks_per_cu(const void* kern, int threads, size_t dyn) {
   cache[key] = nb;
   return nb;
 }
+
+// ofdm_chain_mmse.hip: the MMSE estimator of a plan as one operator W^T [np][m_pad] and its batched application
+int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
+                        int m_pad, std::vector<c64>& wt);
+template <typename T>
+int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames);
 
 // ofdm_chain_pilot.hip: symbol-1 transform + OMP of every frame in one launch (comb pilots, taps <= OMP_RT)
 template <typename T>

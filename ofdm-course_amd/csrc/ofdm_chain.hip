@@ -17,6 +17,8 @@
 // index difference only (closed-form table, double).  The LS refit solves the (<= taps)^2 Gram
 // system by Cholesky in double, b_i = a_i^H y is a double dot product, and the stopping rule uses
 // ||r_{i-1}-r_i||^2 = ||r_{i-1}||^2 - ||r_i||^2 (nested projections).
+#include <cstring>
+
 #include "demap_core.hpp"
 #include "fft_core.hpp"
 
@@ -333,8 +335,13 @@ struct FastPlanView {
   hipEvent_t* ev;
   int comb_lg_up;
   int* fused_out;
+  const void* d_wt;
+  int m_pad;
+  void** ws_h;
 };
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
+int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
+                        int m_pad, std::vector<c64>& wt);                                  // ofdm_chain_mmse.hip
 int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
                    const void* ref, void* errs, void* h_out, void* idx_out);
 }  // namespace ofdm
@@ -345,7 +352,10 @@ struct ofdm_rx_plan {
   int pilots_in_band;
   int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
-  void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr;
+  void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr, *ws_h = nullptr;
+  void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
+  int m_pad = 0;
+  std::vector<int32_t> pilot_loc;      // 1-based, as given
   int64_t ws_frames = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int timing = 0;          // ofdm_rx_plan_set_timing
@@ -416,6 +426,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
   for (int p = 0; p < n_pilots && rc == OFDM_OK; ++p) {
     if (pilot_carriers[p] < 1 || pilot_carriers[p] > nfft) { set_error("rx_plan_create: pilot carrier outside 1..Nfft"); rc = OFDM_ERR_ARG; break; }
     pc0[p] = pilot_carriers[p] - 1;
+    pl->pilot_loc.push_back(pilot_carriers[p]);
     prole[pc0[p]] = (int16_t)p;
     if (pilot_carriers[p] > n_carrier) pl->pilots_in_band = 0;
   }
@@ -479,10 +490,41 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
 int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
-                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx};
+                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   delete pl;
+  return OFDM_OK;
+}
+
+int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double snr_db, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(pl, "rx_plan_set_mmse: null plan");
+  if (!h || n_h <= 0) {                                   // back to OMP mode
+    OFDM_HIP(hipStreamSynchronize(ctx().stream));
+    if (pl->d_wt) { (void)hipFree(pl->d_wt); pl->d_wt = nullptr; }
+    return OFDM_OK;
+  }
+  OFDM_ARG((flags & OFDM_DEVICE) == 0, "rx_plan_set_mmse: h is a host array (the operator is built on the host)");
+  OFDM_ARG(pl->np >= 2, "rx_plan_set_mmse: MMSE_CE needs at least two pilots (MMSE_CE.m:15)");
+  std::vector<c64> hh((size_t)n_h);
+  if (is_f64(flags)) std::memcpy(hh.data(), h, sizeof(c64) * (size_t)n_h);
+  else for (int64_t i = 0; i < n_h; ++i) hh[i] = c64{(double)((const c32*)h)[i].x, (double)((const c32*)h)[i].y};
+  const int m_pad = (pl->n_carrier + 15) & ~15;
+  std::vector<c64> wt;
+  OFDM_TRY(mmse_build_operator(hh.data(), n_h, snr_db, pl->pilot_loc.data(), pl->np, pl->n_carrier, m_pad, wt));
+  OFDM_HIP(hipStreamSynchronize(ctx().stream));
+  if (pl->d_wt) { (void)hipFree(pl->d_wt); pl->d_wt = nullptr; }
+  if (pl->f64) {
+    OFDM_HIP(hipMalloc(&pl->d_wt, sizeof(c64) * wt.size()));
+    OFDM_HIP(hipMemcpy(pl->d_wt, wt.data(), sizeof(c64) * wt.size(), hipMemcpyHostToDevice));
+  } else {
+    std::vector<c32> w32(wt.size());
+    for (size_t i = 0; i < wt.size(); ++i) w32[i] = c32{(float)wt[i].x, (float)wt[i].y};
+    OFDM_HIP(hipMalloc(&pl->d_wt, sizeof(c32) * w32.size()));
+    OFDM_HIP(hipMemcpy(pl->d_wt, w32.data(), sizeof(c32) * w32.size(), hipMemcpyHostToDevice));
+  }
+  pl->m_pad = m_pad;
   return OFDM_OK;
 }
 
@@ -546,10 +588,13 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.ev = pl->timing ? pl->ev : nullptr;
     pv.comb_lg_up = pl->comb_lg_up;
     pv.fused_out = &pl->last_fused;
+    pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
     pl->last_fast = 1;
     OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
     return st.finish();
   }
+  OFDM_ARG(!pl->d_wt, "rx_chain_task5: the MMSE mode of a plan needs Nfft in {512, 1024, 2048, 4096}, pilots inside "
+                      "1..N_carrier and at most 48 Ki decided symbols per frame (ofdm_MMSE_CE covers every other case)");
   pl->last_fast = 0;
   if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[0], ctx().stream));
 #define CALL(NN)                                                                                              \

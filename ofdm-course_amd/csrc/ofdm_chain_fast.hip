@@ -313,7 +313,8 @@ __device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
   else return demap_square<T, BA>(tab, z);
 }
 
-template <typename T, int NW, bool PRUNE2, int BA>
+// HEXT: the channel estimate of every frame comes from P.h_in (MMSE mode) instead of the OMP taps.
+template <typename T, int NW, bool PRUNE2, int BA, bool HEXT = false>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
     if (P.n_symb > 1) frame_load<T, NW>(nx, frx + Lsym + P.t_guard, gid, lane);
     if (gid == 0) sh_err = 0;
     // ---- H = fft(h)(1..N_carrier) from the taps; G = 1 ./ H           (OMP_estimate.m:36, equalize_signal.m:6)
-    if (gid < taps) {
+    //      MMSE mode: H was written by mmse_apply_kernel (ofdm_chain_mmse.hip)
+    if (!HEXT && gid < taps) {
       const int idx = P.tap_idx[f * taps + gid];
       sh_tidx[gid] = idx;
       sh_tx[gid] = P.tap_x[f * taps + gid];
@@ -366,7 +368,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) {
       geq[t] = mk<T>(0, 0);
-      if (kk[t] < P.n_carrier) {
+      if constexpr (HEXT) {
+        if (kk[t] < P.n_carrier) {
+          const cx<T> H = P.h_in[f * P.n_carrier + kk[t]];
+          if (h_out) h_out[f * P.n_carrier + kk[t]] = H;
+          geq[t] = cdiv(mk<T>(1, 0), H);
+        }
+      } else if (kk[t] < P.n_carrier) {
         double hr = 0, hi = 0;
         for (int q = 0; q < taps; ++q) {
           const int idx = sh_tidx[q];
@@ -453,6 +461,9 @@ struct FastPlanView {
   hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
   int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
   int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
+  const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
+  int m_pad;
+  void** ws_h;             // MMSE mode workspace: H [n_frames][n_carrier]
 };
 
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
@@ -475,23 +486,30 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   P.tw = (const cx<T>*)tw;
   // workspace (grown on demand, kept by the plan)
   if (*pv.ws_frames < n_frames) {
-    void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx};
+    void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx, pv.ws_h};
     OFDM_HIP(hipStreamSynchronize(ctx().stream));
     for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     OFDM_HIP(hipMalloc(pv.ws_stash, sizeof(cx<T>) * (size_t)pv.n_carrier * n_frames));
     OFDM_HIP(hipMalloc(pv.ws_ypil, sizeof(cx<T>) * (size_t)pv.np * n_frames));
     OFDM_HIP(hipMalloc(pv.ws_tapidx, sizeof(int32_t) * (size_t)pv.taps * n_frames));
     OFDM_HIP(hipMalloc(pv.ws_tapx, sizeof(c64) * (size_t)pv.taps * n_frames));
+    if (pv.d_wt) OFDM_HIP(hipMalloc(pv.ws_h, sizeof(cx<T>) * (size_t)pv.n_carrier * n_frames));
     *pv.ws_frames = n_frames;
   }
   P.stash = (cx<T>*)*pv.ws_stash; P.ypil = (cx<T>*)*pv.ws_ypil;
   P.tap_idx = (int32_t*)*pv.ws_tapidx; P.tap_x = (c64*)*pv.ws_tapx;
+  const bool mmse = pv.d_wt != nullptr;
+  if (mmse && !*pv.ws_h) {                       // the plan switched to MMSE mode after the workspace was made
+    OFDM_HIP(hipStreamSynchronize(ctx().stream));
+    OFDM_HIP(hipMalloc(pv.ws_h, sizeof(cx<T>) * (size_t)pv.n_carrier * *pv.ws_frames));
+  }
+  P.h_in = mmse ? (const cx<T>*)*pv.ws_h : nullptr;
   DemapTable<T> tab;
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
   const int ncu = ctx().num_cu;
   hipStream_t st = ctx().stream;
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
-  const bool fused = pv.comb_lg_up >= 0 && pv.taps <= OMP_RT && pv.k_atoms <= 512 && !getenv("OFDM_FAST_UNFUSED");
+  const bool fused = !mmse && pv.comb_lg_up >= 0 && pv.taps <= OMP_RT && pv.k_atoms <= 512 && !getenv("OFDM_FAST_UNFUSED");
   if (pv.fused_out) *pv.fused_out = fused ? 1 : 0;
   if (fused) {
     // kernels 1+2 in one launch (comb pilots): c0 by a wave-local inverse transform (ofdm_chain_pilot.hip)
@@ -506,7 +524,9 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     }
     if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
     // kernel 2
-    {
+    if (mmse) {
+      OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
+    } else {
       const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
       OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
       const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
@@ -542,11 +562,20 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
       return OFDM_OK;
     };
     const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
-    switch (ba) {
-      case 2: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 2>)); break;
-      case 3: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 3>)); break;
-      case 4: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 4>)); break;
-      default: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0>)); break;
+    if (mmse) {
+      switch (ba) {
+        case 2: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 2, true>)); break;
+        case 3: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 3, true>)); break;
+        case 4: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 4, true>)); break;
+        default: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0, true>)); break;
+      }
+    } else {
+      switch (ba) {
+        case 2: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 2>)); break;
+        case 3: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 3>)); break;
+        case 4: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 4>)); break;
+        default: OFDM_TRY(launch(rx_symbols_kernel<T, NW, PRUNE2, 0>)); break;
+      }
     }
     OFDM_TRY(check_launch("rx_symbols_kernel"));
   }

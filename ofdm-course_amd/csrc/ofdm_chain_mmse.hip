@@ -1,0 +1,195 @@
+// MMSE mode of the fused RX chain (BASELINE config "comb pilots, MMSE_CE + interpolate, 1M-symbol Monte-Carlo").
+//
+// T5/MMSE_CE.m:1-39 is, for a fixed (h, SNR, pilot layout), ONE linear operator on the pilot LS values of symbol 1:
+//   H_MMSE(1..N_carrier) = Sop * (Rhp(1:Np,:) / Rpp) * H_tilde,   Rpp = rf2 + I/snr,  Rhp(1:Np,:) = rf2
+//                        = Sop * (I - Rpp^-1 / snr) * H_tilde  =:  W * H_tilde
+// (Sop = the not-a-knot spline + end-knot rule of interpolate.m as a real [N_carrier x Np] matrix, spline_op.hpp).
+// The reference rebuilds and solves the Np x Np system for every frame; a Monte-Carlo batch shares (h, SNR), so the
+// plan builds W once on the host in double and every batch is one complex GEMM  H[N_carrier x F] = W * Y[Np x F]
+// -- genuinely GEMM-shaped, so fp32 runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32) in the same
+// real-GEMM form as the OMP dictionary correlation; fp64 (parity mode) uses a plain VALU kernel.
+#include <algorithm>
+#include <complex>
+#include <vector>
+
+#include "chain_fast_core.hpp"
+#include "spline_op.hpp"
+
+namespace ofdm {
+
+using zc = std::complex<double>;
+
+// W^T [np][m_pad] (row index fastest: both kernels read 16 consecutive rows per pilot), rows >= n_carrier are zero.
+int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
+                        int m_pad, std::vector<c64>& wt) {
+  OFDM_ARG(np >= 2 && np <= 512, "rx_plan_set_mmse: 2..512 pilots supported (the operator is built on the host)");
+  OFDM_ARG(n_h >= 1, "rx_plan_set_mmse: empty impulse response");
+  const double snr = std::pow(10.0, snr_db * 0.1);                                 // MMSE_CE.m:13
+  const double nps = (double)pilot_loc[1] - (double)pilot_loc[0];                  // :15
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int64_t k = 0; k < n_h; ++k) {                                              // :19-24
+    const double p = h[k].x * h[k].x + h[k].y * h[k].y;
+    s0 += p; s1 += p * (double)k; s2 += p * (double)k * (double)k;
+  }
+  OFDM_ARG(s0 > 0, "rx_plan_set_mmse: impulse response is all zero");
+  const double r = s1 / s0, r2 = s2 / s0;
+  const double tau_rms = std::sqrt(r2 - r * r);
+  const double c = 2.0 * M_PI * tau_rms * (1.0 / (double)n_carrier) * nps;          // :25-26,:30
+  // Rpp = toeplitz(1 / (1 + j c (i - j))) + I / snr  (:33-35), Hermitian positive definite
+  std::vector<zc> A((size_t)np * np);
+  for (int i = 0; i < np; ++i)
+    for (int j = 0; j < np; ++j) {
+      const double k = (double)(i - j);
+      A[(size_t)i * np + j] = zc(1.0, 0.0) / zc(1.0, c * k) + (i == j ? zc(1.0 / snr, 0) : zc(0, 0));
+    }
+  // Cholesky A = L L^H (lower, in place)
+  for (int j = 0; j < np; ++j) {
+    double d = A[(size_t)j * np + j].real();
+    for (int k = 0; k < j; ++k) d -= std::norm(A[(size_t)j * np + k]);
+    OFDM_ARG(d > 0, "rx_plan_set_mmse: Rpp is not positive definite");
+    const double ljj = std::sqrt(d);
+    A[(size_t)j * np + j] = zc(ljj, 0);
+    for (int i = j + 1; i < np; ++i) {
+      zc s = A[(size_t)i * np + j];
+      for (int k = 0; k < j; ++k) s -= A[(size_t)i * np + k] * std::conj(A[(size_t)j * np + k]);
+      A[(size_t)i * np + j] = s / ljj;
+    }
+  }
+  // X = Rpp^-1 column by column; M = I - X / snr   (rows j, columns p)
+  std::vector<zc> M((size_t)np * np), col(np);
+  for (int p = 0; p < np; ++p) {
+    for (int i = 0; i < np; ++i) {                                                  // L z = e_p
+      zc s = i == p ? zc(1, 0) : zc(0, 0);
+      for (int k = (i > p ? p : i); k < i; ++k) s -= A[(size_t)i * np + k] * col[k];
+      col[i] = i < p ? zc(0, 0) : s / A[(size_t)i * np + i].real();
+    }
+    for (int i = np - 1; i >= 0; --i) {                                             // L^H x = z
+      zc s = col[i];
+      for (int k = i + 1; k < np; ++k) s -= std::conj(A[(size_t)k * np + i]) * col[k];
+      col[i] = s / A[(size_t)i * np + i].real();
+    }
+    for (int j = 0; j < np; ++j) M[(size_t)j * np + p] = (j == p ? zc(1, 0) : zc(0, 0)) - col[j] / snr;
+  }
+  // W = Sop * M  (:38: interpolate(H_MMSE(1:Np), pilot_loc, N_carrier, 'spline'))
+  std::vector<double> sop;                                                          // [n_carrier x np], column-major
+  OFDM_TRY(build_interpolate_operator(pilot_loc, np, n_carrier, 's', sop));
+  wt.assign((size_t)np * m_pad, c64{0, 0});
+  std::vector<zc> rowacc(np);
+  for (int m = 0; m < n_carrier; ++m) {
+    std::fill(rowacc.begin(), rowacc.end(), zc(0, 0));
+    for (int j = 0; j < np; ++j) {
+      const double sj = sop[m + (size_t)j * n_carrier];
+      if (sj == 0.0) continue;
+      const zc* mj = &M[(size_t)j * np];
+      for (int p = 0; p < np; ++p) rowacc[p] += sj * mj[p];
+    }
+    for (int p = 0; p < np; ++p) wt[(size_t)p * m_pad + m] = c64{rowacc[p].real(), rowacc[p].imag()};
+  }
+  return OFDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// H[f][m] = sum_p W[m][p] Y[f][p]
+// fp32: real GEMM  C[M x 2F] = [Wr | Wi] * B,  B(p,re;2f) = Yr, B(p,im;2f) = -Yi, B(p,re;2f+1) = Yi, B(p,im;2f+1) = Yr.
+// One wavefront = 16 rows x 32 frames (four 16x16 tiles: 8 frames each, columns 2f / 2f+1 = Re / Im).  One k-step =
+// 4 pilots = 8 MFMAs; both operands come straight from L2 (W^T: 16 consecutive rows per pilot; Y: 32-byte runs),
+// the next k-step's operands are requested before this step's MFMAs issue.  No LDS: occupancy hides the latency.
+// ---------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* __restrict__ wt, const cx<float>* __restrict__ y,
+                                                              cx<float>* __restrict__ hout, int np, int m_pad, int n_carrier,
+                                                              int64_t n_frames) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i16 = lane & 15, q = lane >> 4, fsub = i16 >> 1, cim = i16 & 1;
+  const int m0 = (blockIdx.y * 4 + wave) * 16;
+  if (m0 >= m_pad) return;                                   // wavefront-uniform
+  const int64_t f0 = (int64_t)blockIdx.x * 32;
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0, 0, 0, 0};
+  const cx<float>* ap = wt + m0 + i16;                        // + p * m_pad
+  const cx<float>* yp[4];
+  bool yv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t f = f0 + 8 * g + fsub;
+    yv[g] = f < n_frames;
+    yp[g] = y + (yv[g] ? f : 0) * np;
+  }
+  cx<float> a = ap[(size_t)q * m_pad], b[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b[g] = yv[g] ? yp[g][q] : mk<float>(0, 0);
+  for (int p0 = 0; p0 < np; p0 += 4) {
+    const int pn = p0 + 4 < np ? p0 + 4 : p0;
+    const cx<float> an = ap[(size_t)(pn + q) * m_pad];
+    cx<float> bn[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bn[g] = yv[g] ? yp[g][pn + q] : mk<float>(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float b_re = cim ? b[g].y : b[g].x;               // multiplies Re(W)
+      const float b_im = cim ? b[g].x : -b[g].y;              // multiplies Im(W)
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b_re, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b_im, acc[g], 0, 0, 0);
+    }
+    a = an;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[g] = bn[g];
+  }
+  // C: lane holds rows 4*(lane>>4)+r of column lane&15
+  float* ho = reinterpret_cast<float*>(hout);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t f = f0 + 8 * g + fsub;
+    if (f < n_frames) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * q + r;
+        if (m < n_carrier) ho[2 * (f * n_carrier + m) + cim] = acc[g][r];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mmse_apply_valu_kernel(const cx<T>* __restrict__ wt, const cx<T>* __restrict__ y,
+                                                              cx<T>* __restrict__ hout, int np, int m_pad, int n_carrier,
+                                                              int64_t n_frames) {
+  // one thread per (carrier, 4 frames): W^T reads coalesce over the carrier, Y values are workgroup-uniform
+  const int m = blockIdx.y * 256 + threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.x * 4;
+  if (m >= n_carrier) return;
+  cx<T> acc[4] = {mk<T>(0, 0), mk<T>(0, 0), mk<T>(0, 0), mk<T>(0, 0)};
+  for (int p = 0; p < np; ++p) {
+    const cx<T> w = wt[(size_t)p * m_pad + m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (f0 + j < n_frames) acc[j] = acc[j] + w * y[(f0 + j) * np + p];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (f0 + j < n_frames) hout[(f0 + j) * n_carrier + m] = acc[j];
+}
+
+template <typename T>
+int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames) {
+  hipStream_t st = ctx().stream;
+  if constexpr (std::is_same<T, float>::value) {
+    if (np % 4 == 0 && m_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA")) {
+      const dim3 grid((unsigned)((n_frames + 31) / 32), (unsigned)((m_pad / 16 + 3) / 4));
+      hipLaunchKernelGGL(mmse_apply_mfma_kernel, grid, dim3(256), 0, st, (const cx<float>*)wt, (const cx<float>*)y,
+                         (cx<float>*)hout, np, m_pad, n_carrier, n_frames);
+      return check_launch("mmse_apply_mfma_kernel");
+    }
+  }
+  const dim3 grid((unsigned)((n_frames + 3) / 4), (unsigned)((n_carrier + 255) / 256));
+  hipLaunchKernelGGL(mmse_apply_valu_kernel<T>, grid, dim3(256), 0, st, (const cx<T>*)wt, (const cx<T>*)y, (cx<T>*)hout, np,
+                     m_pad, n_carrier, n_frames);
+  return check_launch("mmse_apply_valu_kernel");
+}
+
+template int mmse_apply_run<float>(const void*, const void*, void*, int, int, int, int64_t);
+template int mmse_apply_run<double>(const void*, const void*, void*, int, int, int, int64_t);
+
+}  // namespace ofdm
