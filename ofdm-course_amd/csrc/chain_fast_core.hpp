@@ -375,6 +375,38 @@ inline int resident_blocks_per_cu(const void* kern, int threads, size_t dyn) {
   return nb;
 }
 
+// BA = bits per axis of a square QAM (2, 3, 4: the slicer thresholds become compile-time-indexed scalars;
+// with a run-time switch every variant's constants stay live and the kernel spills ~80 SGPRs to VGPR lanes),
+// BA = 0: any constellation through the generic decision function.
+template <typename T, int BA>
+__device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
+  if constexpr (BA == 0) return demap_decide(tab, z);
+  else return demap_square<T, BA>(tab, z);
+}
+
+// What the fast / split paths need to know about an RX plan (ofdm_chain.hip owns the plan)
+struct FastPlanView {
+  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;
+  const void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram;
+  const std::vector<c64>* dict;
+  const ConstellationInfo* cinfo;
+  void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;   // workspace owned by the plan
+  int64_t* ws_frames;
+  hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
+  int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
+  int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
+  const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
+  int m_pad;
+  void** ws_h;             // MMSE mode workspace: H [n_frames][n_carrier]
+  void** ws_x;             // split path workspace: X(1..N_carrier, :) of every symbol [n_frames * n_symb][n_carrier]
+  int64_t* ws_x_elems;
+};
+
+template <typename T>
+int fast_params_prepare(const FastPlanView& pv, const void* tw, int64_t n_frames, FastParams<T>& P);   // ofdm_chain_fast.hip
+template <typename T>
+int omp_batch_run(const FastParams<T>& P, int64_t n_frames);                                            // ofdm_chain_fast.hip
+
 // ofdm_chain_mmse.hip: the MMSE estimator of a plan as one operator W^T [np][m_pad] and its batched application
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
                         int m_pad, std::vector<c64>& wt);

@@ -19,8 +19,7 @@
 // ||r_{i-1}-r_i||^2 = ||r_{i-1}||^2 - ||r_i||^2 (nested projections).
 #include <cstring>
 
-#include "demap_core.hpp"
-#include "fft_core.hpp"
+#include "chain_fast_core.hpp"
 
 namespace ofdm {
 
@@ -325,23 +324,12 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
 using namespace ofdm;
 
 namespace ofdm {
-struct FastPlanView {
-  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;
-  const void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram;
-  const std::vector<c64>* dict;
-  const ConstellationInfo* cinfo;
-  void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;
-  int64_t* ws_frames;
-  hipEvent_t* ev;
-  int comb_lg_up;
-  int* fused_out;
-  const void* d_wt;
-  int m_pad;
-  void** ws_h;
-};
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb);     // ofdm_chain_fast.hip
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
                         int m_pad, std::vector<c64>& wt);                                  // ofdm_chain_mmse.hip
+bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb, bool f64);   // ofdm_chain_split.hip
+int chain_split_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                    const void* ref, void* errs, void* h_out, void* idx_out, const int32_t* d_pc0);
 int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
                    const void* ref, void* errs, void* h_out, void* idx_out);
 }  // namespace ofdm
@@ -353,6 +341,8 @@ struct ofdm_rx_plan {
   int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
   void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr, *ws_h = nullptr;
+  void* ws_x = nullptr;    // split path: X(1..N_carrier, :) of every symbol
+  int64_t ws_x_elems = 0;
   void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
   int m_pad = 0;
   std::vector<int32_t> pilot_loc;      // 1-based, as given
@@ -364,6 +354,21 @@ struct ofdm_rx_plan {
   ConstellationInfo cinfo;
   std::vector<c64> dict;
 };
+
+constexpr size_t GENERIC_LDS_LIMIT = 158 * 1024;
+// dynamic LDS the generic single kernel would ask for (mirrors chain_layout + launch_chain)
+static size_t generic_lds_bytes(const ofdm_rx_plan* pl) {
+  const size_t cs = pl->f64 ? sizeof(c64) : sizeof(c32);
+  size_t b = 0;
+  b += align16(cs * (size_t)fft_lds_elems(pl->nfft));
+  b += align16(cs * (size_t)pl->np);
+  b += align16(cs * (size_t)pl->k_atoms);
+  b += align16(sizeof(c64) * CH_MAXT * 2);
+  b += align16(sizeof(int) * (CH_MAXT + 4));
+  b += align16(sizeof(c64) * (size_t)pl->taps * pl->taps);
+  b += align16((size_t)pl->nd * pl->n_symb);
+  return b * (size_t)fft_xforms_per_wg(pl->nfft);
+}
 
 template <typename T, int N>
 static int launch_chain(const ofdm_rx_plan* pl, const void* tw, const void* rx, int64_t n_frames, void* bits,
@@ -380,7 +385,7 @@ static int launch_chain(const ofdm_rx_plan* pl, const void* tw, const void* rx, 
   constexpr int FPW = fft_xforms_per_wg(N);
   chain_layout<T>(P, N, pl->bps);
   const size_t dyn = (size_t)P.group_bytes * FPW;
-  OFDM_ARG(dyn <= 158 * 1024, "rx_chain_task5: configuration needs %zu bytes of LDS (limit 158 KiB; use fp32 or a smaller frame)", dyn);
+  OFDM_ARG(dyn <= GENERIC_LDS_LIMIT, "rx_chain_task5: configuration needs %zu bytes of LDS (limit 158 KiB; use fp32 or a smaller frame)", dyn);
   OFDM_HIP(hipFuncSetAttribute((const void*)rx_chain_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   hipLaunchKernelGGL((rx_chain_kernel<T, N>), dim3(cdiv_u(n_frames, FPW)), dim3(fft_wg_threads(N)), dyn, ctx().stream,
                      P, (const cx<T>*)rx, n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs,
@@ -490,7 +495,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
 int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
-                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt};
+                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   delete pl;
@@ -575,8 +580,15 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
   OFDM_TRY(st.out(index_out, sizeof(int32_t) * (size_t)pl->taps * n_frames, &didx));
   const void* tw = nullptr;
   OFDM_TRY(get_twiddles(pl->nfft, pl->f64 != 0, &tw));
-  if (pl->pilots_in_band &&
-      chain_fast_supported(pl->nfft, pl->n_carrier, pl->taps, pl->bps, (int64_t)pl->nd * pl->n_symb)) {
+  const bool fast = pl->pilots_in_band &&
+                    chain_fast_supported(pl->nfft, pl->n_carrier, pl->taps, pl->bps, (int64_t)pl->nd * pl->n_symb);
+  // split form: Nfft beyond the wave-local fast path, a frame state that does not fit the generic kernel's LDS, or
+  // MMSE mode outside the fast path
+  bool split = false;
+  if (!fast && pl->pilots_in_band &&
+      chain_split_supported(pl->nfft, pl->n_carrier, pl->taps, pl->bps, (int64_t)pl->nd * pl->n_symb, pl->f64 != 0))
+    split = pl->nfft > 4096 || pl->d_wt != nullptr || generic_lds_bytes(pl) > GENERIC_LDS_LIMIT;
+  if (fast || split) {
     FastPlanView pv;
     pv.nfft = pl->nfft; pv.t_guard = pl->t_guard; pv.n_symb = pl->n_symb; pv.n_carrier = pl->n_carrier;
     pv.np = pl->np; pv.nd = pl->nd; pv.k_atoms = pl->k_atoms; pv.taps = pl->taps; pv.bps = pl->bps;
@@ -589,12 +601,14 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.comb_lg_up = pl->comb_lg_up;
     pv.fused_out = &pl->last_fused;
     pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
+    pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
     pl->last_fast = 1;
-    OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
+    if (fast) OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
+    else OFDM_TRY(chain_split_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx, (const int32_t*)pl->d_pc0));
     return st.finish();
   }
-  OFDM_ARG(!pl->d_wt, "rx_chain_task5: the MMSE mode of a plan needs Nfft in {512, 1024, 2048, 4096}, pilots inside "
-                      "1..N_carrier and at most 48 Ki decided symbols per frame (ofdm_MMSE_CE covers every other case)");
+  OFDM_ARG(!pl->d_wt, "rx_chain_task5: the MMSE mode of a plan needs pilots inside 1..N_carrier, at most 32 taps and a frame "
+                      "whose decisions fit the workgroup's LDS (ofdm_MMSE_CE covers every other case)");
   pl->last_fast = 0;
   if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[0], ctx().stream));
 #define CALL(NN)                                                                                              \

@@ -304,15 +304,6 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // ---------------------------------------------------------------------------------------------
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
-// BA = bits per axis of a square QAM (2, 3, 4: the slicer thresholds become compile-time-indexed scalars;
-// with a run-time switch every variant's constants stay live and the kernel spills ~80 SGPRs to VGPR lanes),
-// BA = 0: any constellation through the generic decision function.
-template <typename T, int BA>
-__device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
-  if constexpr (BA == 0) return demap_decide(tab, z);
-  else return demap_square<T, BA>(tab, z);
-}
-
 // HEXT: the channel estimate of every frame comes from P.h_in (MMSE mode) instead of the OMP taps.
 template <typename T, int NW, bool PRUNE2, int BA, bool HEXT = false>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
@@ -451,20 +442,6 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-struct FastPlanView {
-  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;
-  const void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram;
-  const std::vector<c64>* dict;
-  const ConstellationInfo* cinfo;
-  void **ws_stash, **ws_ypil, **ws_tapidx, **ws_tapx;   // workspace owned by the plan
-  int64_t* ws_frames;
-  hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
-  int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
-  int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
-  const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
-  int m_pad;
-  void** ws_h;             // MMSE mode workspace: H [n_frames][n_carrier]
-};
 
 bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb) {
   if (getenv("OFDM_CHAIN_GENERIC")) return false;
@@ -475,10 +452,10 @@ bool chain_fast_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd
   return true;
 }
 
-template <typename T, int NW, bool PRUNE2>
-static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
-                       const void* ref, void* errs, void* h_out, void* idx_out) {
-  FastParams<T> P;
+// Fills the kernel parameter block of a plan and grows the plan's workspace to n_frames (shared by the fast
+// path here and the split path of ofdm_chain_split.hip).
+template <typename T>
+int fast_params_prepare(const FastPlanView& pv, const void* tw, int64_t n_frames, FastParams<T>& P) {
   P.n_symb = pv.n_symb; P.t_guard = pv.t_guard; P.n_carrier = pv.n_carrier; P.np = pv.np; P.nd = pv.nd;
   P.k_atoms = pv.k_atoms; P.taps = pv.taps; P.frame_words = pv.frame_words; P.bps = pv.bps;
   P.prole = (const int16_t*)pv.d_prole; P.drole = (const int16_t*)pv.d_drole;
@@ -504,6 +481,40 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     OFDM_HIP(hipMalloc(pv.ws_h, sizeof(cx<T>) * (size_t)pv.n_carrier * *pv.ws_frames));
   }
   P.h_in = mmse ? (const cx<T>*)*pv.ws_h : nullptr;
+  return OFDM_OK;
+}
+template int fast_params_prepare<float>(const FastPlanView&, const void*, int64_t, FastParams<float>&);
+template int fast_params_prepare<double>(const FastPlanView&, const void*, int64_t, FastParams<double>&);
+
+// omp_batch_kernel over n_frames frames: pilot LS values P.ypil -> taps P.tap_idx / P.tap_x
+template <typename T>
+int omp_batch_run(const FastParams<T>& P, int64_t n_frames) {
+  hipStream_t st = ctx().stream;
+  const OmpLayout lay = omp_layout<T>(P.np, P.k_atoms, P.taps);
+  OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
+  const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
+  const bool mfma = std::is_same<T, float>::value && (P.k_atoms % 16 == 0) && (P.np % 4 == 0) && lay.fpw >= 2 &&
+                    !getenv("OFDM_OMP_NO_MFMA");
+  if (mfma) {
+    if constexpr (std::is_same<T, float>::value) {
+      OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+      hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+    }
+  } else {
+    OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+    hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+  }
+  return check_launch("omp_batch_kernel");
+}
+template int omp_batch_run<float>(const FastParams<float>&, int64_t);
+template int omp_batch_run<double>(const FastParams<double>&, int64_t);
+
+template <typename T, int NW, bool PRUNE2>
+static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                       const void* ref, void* errs, void* h_out, void* idx_out) {
+  FastParams<T> P;
+  OFDM_TRY(fast_params_prepare<T>(pv, tw, n_frames, P));
+  const bool mmse = pv.d_wt != nullptr;
   DemapTable<T> tab;
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
   const int ncu = ctx().num_cu;
@@ -527,21 +538,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     if (mmse) {
       OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
     } else {
-      const OmpLayout lay = omp_layout<T>(pv.np, pv.k_atoms, pv.taps);
-      OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
-      const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
-      const bool mfma = std::is_same<T, float>::value && (pv.k_atoms % 16 == 0) && (pv.np % 4 == 0) && lay.fpw >= 2 &&
-                        !getenv("OFDM_OMP_NO_MFMA");
-      if (mfma) {
-        if constexpr (std::is_same<T, float>::value) {
-          OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-          hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
-        }
-      } else {
-        OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-        hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
-      }
-      OFDM_TRY(check_launch("omp_batch_kernel"));
+      OFDM_TRY(omp_batch_run<T>(P, n_frames));
     }
   }
   if (pv.ev && !fused) OFDM_HIP(hipEventRecord(pv.ev[2], st));

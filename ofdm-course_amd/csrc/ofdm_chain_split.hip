@@ -1,0 +1,183 @@
+// Split form of the fused Task-5 RX chain for the geometries the wave-local fast path does not take
+// (Nfft = 8192: BASELINE config "sparse 32-tap channel, OMP_estimate"; or a frame whose state does not fit the
+// single generic kernel's LDS).  Four stages, intermediates in HBM restricted to the carriers that are read:
+//
+//   demod_keep_kernel   OFDM_demodulator of every symbol, rows 1..N_carrier kept        (OFDM_demodulator.m:2-10)
+//   pilot_ls_kernel     Y = X(pilotCarriers, 1) ./ pilotValues(:, 1)                    (Task5_part2.m:190)
+//   omp_batch_kernel    batch OMP with the MFMA dictionary correlation (ofdm_chain_fast.hip), or
+//   mmse_apply_*        the plan's MMSE operator (ofdm_chain_mmse.hip)
+//   eq_demap_kernel     H = fft(h)(1..N_carrier) from the taps -> equalize_signal -> get_payload -> demapping
+//                       -> packed bits -> BER numerator                                 (OMP_estimate.m:25-36, ...)
+//
+// Against the generic single kernel this replaces the O(taps * K * Np) residual correlations by the Gram-table
+// form (O(K * taps^2)) and runs the transform at full occupancy; it costs one write + read of X(1..N_carrier,:).
+#include <algorithm>
+
+#include "chain_fast_core.hpp"
+
+namespace ofdm {
+
+int demod_keep_device(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, int n_keep, bool f64);   // ofdm_modem.hip
+
+template <typename T>
+__global__ __launch_bounds__(256) void pilot_ls_kernel(FastParams<T> P, const cx<T>* __restrict__ xk,
+                                                       const int32_t* __restrict__ pc0, int64_t n_frames) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_frames * P.np) return;
+  const int64_t f = i / P.np;
+  const int p = (int)(i - f * P.np);
+  P.ypil[i] = cdiv(xk[f * P.n_symb * (int64_t)P.n_carrier + pc0[p]], P.pilots[p]);
+}
+
+// one workgroup per frame (grid-stride): G = 1 ./ H in LDS, then every symbol's data carriers
+template <typename T, int BA, bool HEXT>
+__global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft, const cx<T>* __restrict__ xk,
+                                                       int64_t n_frames, uint32_t* __restrict__ bits_out,
+                                                       const uint32_t* __restrict__ ref_bits,
+                                                       uint32_t* __restrict__ errors_out, cx<T>* __restrict__ h_out,
+                                                       int32_t* __restrict__ index_out, DemapTable<T> tab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* geq = (cx<T>*)smem;                                            // [n_carrier]
+  uint8_t* codes = (uint8_t*)(geq + P.n_carrier);                       // [n_symb * nd] (+ padding to 32)
+  __shared__ unsigned int sh_err;
+  __shared__ int sh_tidx[FAST_MAXT];
+  __shared__ c64 sh_tx[FAST_MAXT];
+  const int gid = threadIdx.x;
+  const int taps = P.taps, nd = P.nd, nc = P.n_carrier;
+  const int bps = BA > 0 ? 2 * BA : P.bps;
+  const int n_codes = nd * P.n_symb;
+  const int n_groups = (n_codes + 31) >> 5;
+  if (gid < 32) codes[((n_codes + 31) & ~31) - 32 + gid] = 0;          // zero padding of the last 32-symbol group
+  __syncthreads();
+  for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    if (gid == 0) sh_err = 0;
+    if (!HEXT && gid < taps) {
+      const int idx = P.tap_idx[f * taps + gid];
+      sh_tidx[gid] = idx;
+      sh_tx[gid] = P.tap_x[f * taps + gid];
+      if (index_out) index_out[f * taps + gid] = idx + 1;
+    }
+    __syncthreads();
+    for (int k = gid; k < nc; k += 256) {
+      cx<T> H;
+      if constexpr (HEXT) {
+        H = P.h_in[f * nc + k];
+      } else {
+        double hr = 0, hi = 0;
+        for (int q = 0; q < taps; ++q) {
+          const int idx = sh_tidx[q];
+          const c64 x = sh_tx[q];                                      // zero for unused / overwritten slots
+          const cx<T> w = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * k) & (nfft - 1))];
+          hr += x.x * (double)w.x - x.y * (double)w.y;
+          hi += x.x * (double)w.y + x.y * (double)w.x;
+        }
+        H = mk<T>((T)hr, (T)hi);
+      }
+      if (h_out) h_out[f * nc + k] = H;
+      geq[k] = cdiv(mk<T>(1, 0), H);
+    }
+    __syncthreads();
+    const cx<T>* xf = xk + f * P.n_symb * (int64_t)nc;
+    for (int s = 0; s < P.n_symb; ++s)
+      for (int k = gid; k < nc; k += 256) {
+        const int d = P.drole[k];
+        if (d >= 0) codes[s * nd + d] = (uint8_t)slice_symbol<T, BA>(tab, xf[(int64_t)s * nc + k] * geq[k]);
+      }
+    __syncthreads();
+    unsigned int err = 0;
+    for (int grp = gid; grp < n_groups; grp += 256) {
+      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
+      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
+      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+      unsigned long long acc = 0;
+      int nb = 0, w = grp * bps;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const uint32_t code = (cw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+        acc = (acc << bps) | code;
+        nb += bps;
+        if (nb >= 32) {
+          nb -= 32;
+          const uint32_t word = __builtin_bswap32((uint32_t)(acc >> nb));
+          if (w < P.frame_words) {
+            if (bits_out) bits_out[f * P.frame_words + w] = word;
+            if (ref_bits) err += __popc(word ^ ref_bits[f * P.frame_words + w]);
+          }
+          ++w;
+        }
+      }
+    }
+    if (ref_bits && errors_out) {
+      if (err) atomicAdd(&sh_err, err);
+      __syncthreads();
+      if (gid == 0) errors_out[f] = sh_err;
+    }
+    __syncthreads();
+  }
+}
+
+bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb, bool f64) {
+  if (getenv("OFDM_CHAIN_GENERIC")) return false;
+  if (taps > FAST_MAXT || bps > 8) return false;
+  const size_t lds = (size_t)(f64 ? 16 : 8) * n_carrier + (((size_t)nd_nsymb + 31) & ~size_t(31));
+  (void)nfft;
+  return lds <= 120 * 1024;
+}
+
+template <typename T>
+static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                     const void* ref, void* errs, void* h_out, void* idx_out, const int32_t* d_pc0) {
+  FastParams<T> P;
+  OFDM_TRY(fast_params_prepare<T>(pv, tw, n_frames, P));
+  const bool mmse = pv.d_wt != nullptr;
+  const int64_t need = n_frames * pv.n_symb * (int64_t)pv.n_carrier;
+  if (*pv.ws_x_elems < need) {
+    OFDM_HIP(hipStreamSynchronize(ctx().stream));
+    if (*pv.ws_x) { (void)hipFree(*pv.ws_x); *pv.ws_x = nullptr; }
+    OFDM_HIP(hipMalloc(pv.ws_x, sizeof(cx<T>) * (size_t)need));
+    *pv.ws_x_elems = need;
+  }
+  cx<T>* xk = (cx<T>*)*pv.ws_x;
+  hipStream_t st = ctx().stream;
+  if (pv.fused_out) *pv.fused_out = 0;
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
+  OFDM_TRY(demod_keep_device(rx, xk, pv.nfft, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, pv.f64 != 0));
+  hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
+                     n_frames);
+  OFDM_TRY(check_launch("pilot_ls_kernel"));
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
+  if (mmse) OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
+  else OFDM_TRY(omp_batch_run<T>(P, n_frames));
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
+  DemapTable<T> tab;
+  fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
+  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+  auto launch = [&](auto kern) -> int {
+    const int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), dyn, st, P, pv.nfft, (const cx<T>*)xk, n_frames, (uint32_t*)bits,
+                       (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
+    return OFDM_OK;
+  };
+  const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
+#define SPLIT_CASE(BAV)                                                                                    \
+  if (mmse) OFDM_TRY(launch(eq_demap_kernel<T, BAV, true>)); else OFDM_TRY(launch(eq_demap_kernel<T, BAV, false>))
+  switch (ba) {
+    case 2: SPLIT_CASE(2); break;
+    case 3: SPLIT_CASE(3); break;
+    case 4: SPLIT_CASE(4); break;
+    default: SPLIT_CASE(0); break;
+  }
+#undef SPLIT_CASE
+  OFDM_TRY(check_launch("eq_demap_kernel"));
+  if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
+  return OFDM_OK;
+}
+
+int chain_split_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
+                    const void* ref, void* errs, void* h_out, void* idx_out, const int32_t* d_pc0) {
+  if (pv.f64) return split_run<double>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out, d_pc0);
+  return split_run<float>(pv, tw, rx, n_frames, bits, ref, errs, h_out, idx_out, d_pc0);
+}
+
+}  // namespace ofdm

@@ -32,6 +32,33 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void demod_kernel(const cx<T>* _
   }
 }
 
+// Same transform, keeping only rows 1..n_keep of every column (the carriers the RX chain reads afterwards:
+// equalize_signal.m:6 touches 1..N_carrier only) -- x is [n_keep x n_symb].
+template <typename T, int N>
+__global__ __launch_bounds__(fft_wg_threads(N)) void demod_keep_kernel(const cx<T>* __restrict__ y,
+                                                                       cx<T>* __restrict__ x,
+                                                                       const cx<T>* __restrict__ tw,
+                                                                       int64_t n_symb, int t_guard, int n_keep) {
+  constexpr int TPX = N / 8;
+  constexpr int XPW = fft_xforms_per_wg(N);
+  __shared__ cx<T> lds[XPW * fft_lds_elems(N)];
+  const int g = threadIdx.x / TPX;
+  const int j = threadIdx.x % TPX;
+  const int64_t s = (int64_t)blockIdx.x * XPW + g;
+  const bool live = s < n_symb;
+  cx<T> v[8];
+  const cx<T>* src = y + (live ? s : 0) * (int64_t)(N + t_guard) + t_guard;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = live ? src[j + e * TPX] : mk<T>(0, 0);
+  wg_fft<T, N, false>(v, j, tw, lds + g * fft_lds_elems(N));
+  if (live) {
+    cx<T>* dst = x + s * (int64_t)n_keep;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (j + e * TPX < n_keep) dst[j + e * TPX] = v[e];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // OFDM_modulator -- T5/OFDM_modulator.m:2-11: ifft per column (1/N), CP = last Tg rows prepended.
 // ---------------------------------------------------------------------------------------------
@@ -138,6 +165,27 @@ int demod_device(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, 
 #define CALL(NN)                                                                  \
   if (f64) OFDM_TRY((launch_demod<double, NN>(y, x, tw, n_symb, t_guard)));       \
   else OFDM_TRY((launch_demod<float, NN>(y, x, tw, n_symb, t_guard)));
+  OFDM_FFT_DISPATCH(nfft, CALL)
+#undef CALL
+  return OFDM_OK;
+}
+
+template <typename T, int N>
+static int launch_demod_keep(const void* y, void* x, const void* tw, int64_t n_symb, int t_guard, int n_keep) {
+  constexpr int XPW = fft_xforms_per_wg(N);
+  dim3 grid(cdiv_u(n_symb, XPW)), block(fft_wg_threads(N));
+  hipLaunchKernelGGL((demod_keep_kernel<T, N>), grid, block, 0, ctx().stream, (const cx<T>*)y, (cx<T>*)x,
+                     (const cx<T>*)tw, n_symb, t_guard, n_keep);
+  return check_launch("demod_keep_kernel");
+}
+
+int demod_keep_device(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, int n_keep, bool f64) {
+  if (n_symb == 0) return OFDM_OK;
+  const void* tw = nullptr;
+  OFDM_TRY(get_twiddles(nfft, f64, &tw));
+#define CALL(NN)                                                                             \
+  if (f64) OFDM_TRY((launch_demod_keep<double, NN>(y, x, tw, n_symb, t_guard, n_keep)));     \
+  else OFDM_TRY((launch_demod_keep<float, NN>(y, x, tw, n_symb, t_guard, n_keep)));
   OFDM_FFT_DISPATCH(nfft, CALL)
 #undef CALL
   return OFDM_OK;

@@ -104,8 +104,7 @@ def test_chain_device_flavour_and_batch_independence(ofdm, oracle):
 
 def test_chain_config_c5_shape(ofdm, oracle):
     """BASELINE config 5 geometry: Nfft 8192, 256-QAM, sparse 32-tap channel, OMP with 32 taps, K = Np = 512
-    (generic fused kernel: Nfft 8192 is outside the 512*{1,2,4,8} fast path; fp32 because one workgroup
-    holds the whole frame state in LDS and the fp64 transform alone needs 147 KB)."""
+    (split form: Nfft 8192 is outside the 512*{1,2,4,8} wave-local fast path)."""
     from ofdm_course_amd import frames as fr
     cfg = fr.config_C5()
     nfr = 2
@@ -125,9 +124,62 @@ def test_chain_config_c5_shape(ofdm, oracle):
     assert rel_l2(H, ref["H"]) < 5e-3
     got_bits = fr.unpack_bits(np.asarray(out["bits"]), data["bits"].shape[1])
     assert np.mean(got_bits != ref["bits"]) < 5e-3
-    with pytest.raises(ofdm.OfdmError):
-        fr.make_plan(cfg, ofdm, precision="fp64") and ofdm.rx_chain_task5(
-            fr.make_plan(cfg, ofdm, precision="fp64"), np.asarray(data["rx"]).astype(np.complex128))
+    # fp64 (parity mode): the split form has no LDS limit at this size; picks and bits must be the oracle's
+    plan64 = fr.make_plan(cfg, ofdm, precision="fp64")
+    out64 = ofdm.rx_chain_task5(plan64, np.asarray(data["rx"]).astype(np.complex128), ref_bits_packed=data["packed"],
+                                want_h=True, want_index=True)
+    idx64 = np.asarray(out64["index"]).T
+    for f in range(nfr):
+        want = list(ref["index"][f])
+        assert list(idx64[f][: len(want)]) == want
+    assert rel_l2(np.asarray(out64["H"]).T, ref["H"]) < 1e-8
+    assert np.array_equal(np.asarray(out64["errors"]).astype(np.int64), ref["errors"])
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+@pytest.mark.parametrize("mode", ["omp", "mmse"])
+def test_chain_split_form_8192(ofdm, oracle, precision, mode):
+    """Nfft = 8192 runs the split form (demod_keep -> pilot LS -> batch OMP | MMSE operator -> equalise + demap):
+    a small frame so the oracle is quick; ragged batch."""
+    from ofdm_course_amd import frames as fr
+    cfg = fr.config_small(nfft=8192, n_carrier=600, comb=8, const="16QAM", n_symb=3, dominant_taps=3)
+    cfg.SNR_dB = 24.0
+    nfr = 7
+    data = fr.make_frames(cfg, ofdm, nfr, seed=9, precision=precision)
+    plan = fr.make_plan(cfg, ofdm, precision=precision)
+    tol = 1e-9 if precision == "fp64" else 2e-4
+    if mode == "omp":
+        out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=True)
+        ref = oracle.rx_chain_task5(np.asarray(data["rx"]).astype(np.complex128), cfg.Nfft, cfg.T_guard, cfg.N_carrier,
+                                    cfg.pilotCarriers, cfg.dataCarriers, data["pilots"], cfg.K, cfg.dominant_taps,
+                                    cfg.Constellation, ref_bits=data["bits"])
+        idx = np.asarray(out["index"]).T
+        for f in range(nfr):
+            want = list(ref["index"][f])
+            assert list(idx[f][: len(want)]) == want and not idx[f][len(want):].any()
+        assert rel_l2(np.asarray(out["H"]).T, ref["H"]) < tol
+        errs = np.asarray(out["errors"]).astype(np.int64)
+        assert np.array_equal(errs, ref["errors"]) if precision == "fp64" else np.max(np.abs(errs - ref["errors"])) <= 2
+    else:
+        h, _ = ofdm.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+        hh = np.zeros(cfg.N_carrier, dtype=np.complex128)
+        hh[: len(h)] = h
+        plan.set_mmse(hh, cfg.SNR_dB)
+        out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True)
+        got_bits = fr.unpack_bits(np.asarray(out["bits"]), data["bits"].shape[1])
+        pv = np.repeat(data["pilots"][:, None], cfg.N_symb, axis=1)
+        bad = 0
+        for f in range(nfr):
+            rx = np.asarray(data["rx"])[:, f].astype(np.complex128).reshape((cfg.Nfft + cfg.T_guard, cfg.N_symb), order="F")
+            X = oracle.OFDM_demodulator(rx, cfg.T_guard)
+            Hm = oracle.MMSE_CE(X, pv, cfg.pilotCarriers, cfg.Nfft, cfg.N_carrier, hh, cfg.SNR_dB)
+            Hm = Hm[0] if isinstance(Hm, tuple) else Hm
+            assert rel_l2(np.asarray(out["H"])[:, f], Hm) < tol
+            eq = oracle.equalize_signal(X, Hm, cfg.N_carrier)
+            want = np.asarray(oracle.demapping(0, oracle.get_payload(eq, cfg.dataCarriers).ravel(order="F"),
+                                               cfg.Constellation)).ravel()
+            bad += np.count_nonzero(got_bits[f] != want)
+        assert bad == 0 if precision == "fp64" else bad <= 2 * nfr
 
 
 @pytest.mark.parametrize("precision", ["fp64", "fp32"])
@@ -203,8 +255,8 @@ def test_chain_mmse_mode_errors(ofdm):
     plan = fr.make_plan(cfg, ofdm, precision="fp64")
     plan.set_mmse(np.array([1.0, 0.5]), 20.0)
     data = fr.make_frames(cfg, ofdm, 2, seed=1, precision="fp64")
-    with pytest.raises(ofdm.OfdmError):                            # Nfft 256 is outside the fast-path geometry
-        ofdm.rx_chain_task5(plan, data["rx"])
+    out = ofdm.rx_chain_task5(plan, data["rx"])                    # Nfft 256: MMSE mode takes the split form
+    assert np.asarray(out["bits"]).shape[0] == 2
     with pytest.raises(ofdm.OfdmError):
         plan.set_mmse(np.zeros(4), 20.0)                           # all-zero impulse response
 

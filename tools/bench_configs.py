@@ -163,19 +163,36 @@ def c4():
 
 def c5():
     cfg = fr.config_C5()
-    F = 512
+    F = 2048
     data = fr.make_frames(cfg, ofdm, F, seed=5, precision="fp32", device=dev)
     plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
     ref = torch.from_numpy(data["packed"]).to(dev)
-    ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=5)
     nsym = F * cfg.N_symb
     _, bps = ofdm.constellation_func(cfg.Constellation)
     b_sym = (cfg.Nfft + cfg.T_guard) * 8 + 2 * len(cfg.dataCarriers) * bps / 8 + len(cfg.pilotCarriers) * 8 / cfg.N_symb
-    flops = F * cfg.dominant_taps * 8 * cfg.K * len(cfg.pilotCarriers)
-    return {"config": "C5", "Nfft": cfg.Nfft, "frames": F, "dtype": "f32", "ms": ms, "sym_per_s": nsym / ms * 1e3,
-            "hbm_frac": b_sym * nsym / (ms * 1e-3) / 1e9 / HBM, "omp_correlation_tflops": flops / (ms * 1e-3) / 1e12,
-            "BER": float(out["errors"].sum().item()) / (F * data["bits"].shape[1]),
-            "note": "generic single-kernel path (rx_chain_kernel<float, 8192>), OMP with 32 taps dominates"}
+    res = {"config": "C5", "Nfft": cfg.Nfft, "frames": F, "dtype": "f32"}
+    for name, env in (("split", None), ("generic_single_kernel", "1")):
+        if env:
+            os.environ["OFDM_CHAIN_GENERIC"] = env
+        else:
+            os.environ.pop("OFDM_CHAIN_GENERIC", None)
+        ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=5 if env is None else 2,
+                        warm=2 if env is None else 1)
+        r = {"ms": ms, "sym_per_s": nsym / ms * 1e3, "hbm_frac": b_sym * nsym / (ms * 1e-3) / 1e9 / HBM,
+             "BER": float(out["errors"].sum().item()) / (F * data["bits"].shape[1])}
+        if env is None:
+            plan.set_timing(True)
+            k = []
+            for _ in range(5):
+                ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref)
+                k.append(plan.last_kernel_ms())
+            plan.set_timing(False)
+            k = np.mean(np.array(k), axis=0)
+            r["kernels_ms"] = {"demod_keep+pilot_ls": float(k[0]), "omp_batch_kernel": float(k[1]),
+                               "eq_demap_kernel": float(k[2])}
+        res[name] = r
+    os.environ.pop("OFDM_CHAIN_GENERIC", None)
+    return res
 
 
 if __name__ == "__main__":
