@@ -80,9 +80,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 // frames per wavefront, chosen on the host from the LDS the per-frame state needs).
 //   stage 1: c0 = S^H Y for all FB frames as one real GEMM on the matrix cores
 //   stage 2: each wavefront runs the OMP iterations of FPW frames SIDE BY SIDE: a frame is a group
-//            of LPF = 64/FPW lanes (arg-max by xor-shuffles inside the group); the short serial part
-//            (Cholesky row, two triangular solves) runs on the first lane of every group, i.e. for FPW
-//            frames at once.  Solve arithmetic is in the data precision T (double in parity mode).
+//            of LPF = 64/FPW lanes (arg-max by DPP butterflies inside the group).  Up to 8 taps the refit
+//            is register-resident and redundant per lane (omp_frame_reg); beyond, the state lives in LDS
+//            and the refit is spread over the group's lanes with R = L^-1 updated in place.
+//            Solve arithmetic is in the data precision T (double in parity mode).
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -94,8 +95,8 @@ struct OmpLayout {          // byte offsets into dynamic LDS
 template <typename T>
 static OmpLayout omp_layout(int np, int k_atoms, int taps) {
   OmpLayout o;
-  // per frame: L (taps*taps), z, x (taps each) complex T; picks (taps ints); ctl (n, stop) + rho (double)
-  o.state_bytes = (unsigned)((sizeof(cx<T>) * ((size_t)taps * taps + 2 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
+  // per frame: R (taps*taps), z, x, l (taps each) complex T; picks (taps ints); ctl (n, stop) + rho (double)
+  o.state_bytes = (unsigned)((sizeof(cx<T>) * ((size_t)taps * taps + 3 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
   const size_t per_frame = sizeof(cx<T>) * (np + 1) + sizeof(cx<T>) * k_atoms + o.state_bytes;
   int fpw = 4;                // 16 frames per workgroup: 2 workgroups per CU keep 8 wavefronts in flight
   if (const char* e = getenv("OFDM_OMP_FPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) fpw = v; }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     const int i16 = lane & 15, q = lane >> 4;
     const int fsub = i16 >> 1, cim = i16 & 1;
     const int n_tiles = K / 16;
-    const int n_cg = FB / 8;                       // 16-column groups (8 frames each): 1, 2 or 4
+    const int n_cg = (FB + 7) / 8;                 // 16-column groups (8 frames each): 1, 2 or 4 (FB = 4: half of one)
     for (int tile0 = wave * 2; tile0 < n_tiles; tile0 += 8) {
       const bool two = tile0 + 1 < n_tiles;
       f32x4 acc[2][4];
@@ -149,30 +150,46 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
       const cx<T>* a0p = P.sct + tile0 * 16 + i16;
-      cx<T> a0 = a0p[(size_t)q * K], a1 = two ? a0p[(size_t)q * K + 16] : mk<T>(0, 0);
-      for (int p0 = 0; p0 < np; p0 += 4) {
-        // prefetch the next k-step's A operands while this step's MFMAs issue
-        const int pn = p0 + 4 < np ? p0 + 4 : p0;
-        const cx<T> n0 = a0p[(size_t)(pn + q) * K], n1 = two ? a0p[(size_t)(pn + q) * K + 16] : mk<T>(0, 0);
+      // The A operands come from L2 (the dictionary is shared by every workgroup); PD k-steps are kept in flight in
+      // statically indexed registers (the loop is unrolled by PD): with one step in flight the stage was bound by
+      // one L2 round trip per 4 pilots.
+      constexpr int PD = 4;
+      cx<T> aq0[PD], aq1[PD];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (g < n_cg) {
-            const cx<T> yv = Yl[(g * 8 + fsub) * YS + p0 + q];
-            const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
-            const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
-            acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc[0][g], 0, 0, 0);
-            acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc[0][g], 0, 0, 0);
-            acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc[1][g], 0, 0, 0);
-            acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc[1][g], 0, 0, 0);
+      for (int d = 0; d < PD; ++d) {
+        const int pl = 4 * d < np ? 4 * d : 0;
+        aq0[d] = a0p[(size_t)(pl + q) * K];
+        aq1[d] = two ? a0p[(size_t)(pl + q) * K + 16] : mk<T>(0, 0);
+      }
+      for (int pb = 0; pb < np; pb += 4 * PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int p0 = pb + 4 * d;
+          if (p0 >= np) break;                                   // uniform
+          const cx<T> a0 = aq0[d], a1 = aq1[d];
+          const int pn = p0 + 4 * PD < np ? p0 + 4 * PD : p0;    // refill this slot for PD steps ahead
+          aq0[d] = a0p[(size_t)(pn + q) * K];
+          aq1[d] = two ? a0p[(size_t)(pn + q) * K + 16] : mk<T>(0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (g < n_cg) {
+              const cx<T> yv = g * 8 + fsub < FB ? Yl[(g * 8 + fsub) * YS + p0 + q] : mk<T>(0, 0);
+              const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
+              const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
+              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc[0][g], 0, 0, 0);
+              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc[0][g], 0, 0, 0);
+              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc[1][g], 0, 0, 0);
+              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc[1][g], 0, 0, 0);
+            }
           }
         }
-        a0 = n0; a1 = n1;
       }
       float* c0f = (float*)c0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (g < n_cg) {
           const int fcol = g * 8 + fsub;
+          if (fcol >= FB) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             c0f[2 * (fcol * K + tile0 * 16 + 4 * q + r) + cim] = acc[0][g][r];
@@ -197,10 +214,11 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
   const int64_t f = f0 + fi;
   const bool live = f < n_frames;
   unsigned char* sb = smem + lay.off_state + (size_t)fi * lay.state_bytes;
-  cx<T>* Lm = (cx<T>*)sb;                        // [taps][taps] lower Cholesky factor; diagonal holds 1/L[j][j]
+  cx<T>* Lm = (cx<T>*)sb;                        // [taps][taps] R = L^-1 (lower triangular), generic path only
   cx<T>* zv = Lm + (size_t)taps * taps;          // L z = b
   cx<T>* xv = zv + taps;                         // L^H x = z
-  int* picks = (int*)(xv + taps);
+  cx<T>* lv = xv + taps;                         // new Cholesky row (scratch)
+  int* picks = (int*)(lv + taps);
   int* ctl = picks + ((taps + 1) & ~1);          // [0] picks made, [1] stopped, [2..3] residual energy (double)
   const cx<T>* yf = Yl + fi * YS;
   const cx<T>* cf = c0 + fi * K;
@@ -214,7 +232,12 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     omp_frame_reg<T>(P, cf, gl, K, taps, LPF, sl, live, ynorm, f);
     return;
   }
-  // ---- generic path (more than 8 taps): per-frame state in LDS, serial solve on the group's first lane
+  // ---- generic path (more than 8 taps): per-frame state in LDS, every step spread over the group's lanes.
+  // The LS refit keeps R = L^-1 (inverse of the Cholesky factor of the picked atoms' Gram) instead of L, which turns
+  // the two triangular solves into O(n) work per lane: with row l = G(n, 0..n-1) R^H of the new Cholesky row
+  //   lambda^2 = G(n,n) - |l|^2,   z_n = (c0(kp) - l z) / lambda,   R(n, j) = -(1/lambda) sum_{k>=j} l_k R(k, j),
+  //   x_j += conj(R(n, j)) z_n  (j < n),   x_n = z_n / lambda                      (x = L^-H z = R^H z)
+  auto group_sum = [&](T v) { for (int off = LPF >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64); return v; };
   for (int it = 0; it < taps; ++it) {
     const int n = ctl[0];
     const bool active = ctl[1] == 0;
@@ -233,53 +256,60 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
         if (sc > bs) { bs = sc; bi = k; }
       }
     }
-    for (int off = LPF >> 1; off > 0; off >>= 1) {
-      const float os = __shfl_xor(bs, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-    }
+    const float gmax = group_max_f(bs, LPF, lane);
+    bi = group_min_i(bs == gmax ? bi : 0x7fffffff, LPF, lane);
     const int kp = bi < K ? bi : 0;                // all-NaN scores: MATLAB max returns index 1
-    if (sl == 0 && active) {
+    if (active) {                                  // group-uniform
       int dup = -1;
       for (int qq = 0; qq < n; ++qq) if (picks[qq] == kp) dup = qq;
       if (dup >= 0) {
         // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
-        const cx<T> half = xv[dup] * (T)0.5;
-        xv[dup] = half; xv[n] = half; picks[n] = kp;
-        ctl[0] = n + 1; ctl[1] = 1;
+        wave_sync();
+        if (sl == 0) {
+          const cx<T> half = xv[dup] * (T)0.5;
+          xv[dup] = half; xv[n] = half; picks[n] = kp;
+          ctl[0] = n + 1; ctl[1] = 1;
+        }
       } else {
-        picks[n] = kp;
-        // new Cholesky row: G[n][j] = a_n^H a_j = gram[idx_j - idx_n]
-        T dd = g0;
-        for (int jq = 0; jq < n; ++jq) {
-          const int d = picks[jq] - kp;
-          cx<T> s = d >= 0 ? gl[d] : conj(gl[-d]);
-          for (int k2 = 0; k2 < jq; ++k2) s = s - mulc(Lm[n * taps + k2], Lm[jq * taps + k2]);
-          const cx<T> l = s * Lm[jq * taps + jq].x;             // times 1/L[jq][jq]
-          Lm[n * taps + jq] = l;
-          dd -= norm2(l);
+        // l_j = sum_{k<=j} G(n,k) conj(R(j,k)),  G(n,k) = a_n^H a_k = gram[idx_k - idx_n]
+        T nrm = T(0);
+        cx<T> lz = mk<T>(0, 0);
+        for (int j = sl; j < n; j += LPF) {
+          cx<T> l = mk<T>(0, 0);
+          for (int k = 0; k <= j; ++k) {
+            const int d = picks[k] - kp;
+            const cx<T> g = d >= 0 ? gl[d] : conj(gl[-d]);
+            l = l + mulc(g, Lm[j * taps + k]);
+          }
+          lv[j] = l;
+          nrm += norm2(l);
+          lz = lz + l * zv[j];
         }
-        const T inv_lnn = T(1) / sqrt(dd);
-        Lm[n * taps + n] = mk<T>(inv_lnn, 0);
-        // forward substitution (only the new entry changes): b_n = a_n^H y = c0[kp]
-        cx<T> s = cf[kp];
-        for (int k2 = 0; k2 < n; ++k2) s = s - Lm[n * taps + k2] * zv[k2];
-        const cx<T> zn = s * inv_lnn;
-        zv[n] = zn;
-        // back substitution L^H x = z
-        for (int r = n; r >= 0; --r) {
-          cx<T> a = zv[r];
-          for (int k2 = r + 1; k2 <= n; ++k2) a = a - mulc(xv[k2], Lm[k2 * taps + r]);
-          xv[r] = a * Lm[r * taps + r].x;
+        nrm = group_sum(nrm);
+        lz.x = group_sum(lz.x);
+        lz.y = group_sum(lz.y);
+        const T inv = T(1) / sqrt(g0 - nrm);
+        const cx<T> zn = (cf[kp] - lz) * inv;      // b_n = a_n^H y = c0[kp]
+        wave_sync();                               // lv visible to the whole group
+        for (int j = sl; j < n; j += LPF) {
+          cx<T> r = mk<T>(0, 0);
+          for (int k = j; k < n; ++k) r = r + lv[k] * Lm[k * taps + j];
+          r = r * (-inv);
+          Lm[n * taps + j] = r;
+          xv[j] = xv[j] + conj(r) * zn;
         }
-        // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
-        const double rho_prev = ((double*)(ctl + 2))[0];
-        const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
-        int stop = 0;
-        if (it >= 1 && (!(num > 0.0) || sqrt(num / rho_prev) < 1e-2)) stop = 1;
-        ((double*)(ctl + 2))[0] = rho_prev - num;
-        ctl[0] = n + 1;
-        ctl[1] = stop;
+        if (sl == 0) {
+          Lm[n * taps + n] = mk<T>(inv, 0);
+          xv[n] = zn * inv;
+          zv[n] = zn;
+          picks[n] = kp;
+          // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
+          const double rho_prev = ((double*)(ctl + 2))[0];
+          const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
+          ((double*)(ctl + 2))[0] = rho_prev - num;
+          ctl[0] = n + 1;
+          ctl[1] = (it >= 1 && (!(num > 0.0) || num < 1e-4 * rho_prev)) ? 1 : 0;
+        }
       }
     }
     wave_sync();
@@ -493,8 +523,7 @@ int omp_batch_run(const FastParams<T>& P, int64_t n_frames) {
   const OmpLayout lay = omp_layout<T>(P.np, P.k_atoms, P.taps);
   OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
   const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
-  const bool mfma = std::is_same<T, float>::value && (P.k_atoms % 16 == 0) && (P.np % 4 == 0) && lay.fpw >= 2 &&
-                    !getenv("OFDM_OMP_NO_MFMA");
+  const bool mfma = std::is_same<T, float>::value && (P.k_atoms % 16 == 0) && (P.np % 4 == 0) && !getenv("OFDM_OMP_NO_MFMA");
   if (mfma) {
     if constexpr (std::is_same<T, float>::value) {
       OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
