@@ -64,12 +64,20 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
         H = P.h_in[f * nc + k];
       } else {
         double hr = 0, hi = 0;
-        for (int q = 0; q < taps; ++q) {
-          const int idx = sh_tidx[q];
-          const c64 x = sh_tx[q];                                      // zero for unused / overwritten slots
-          const cx<T> w = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * k) & (nfft - 1))];
-          hr += x.x * (double)w.x - x.y * (double)w.y;
-          hi += x.x * (double)w.y + x.y * (double)w.x;
+        for (int q0 = 0; q0 < taps; q0 += 8) {                         // eight delays at a time: their twiddles in flight together
+          cx<T> w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int idx = q0 + j < taps ? sh_tidx[q0 + j] : -1;
+            w[j] = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * k) & (nfft - 1))];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int q = q0 + j;
+            const c64 x = (q < taps && sh_tidx[q] >= 0) ? sh_tx[q] : c64{0, 0};   // zero for unused / overwritten slots
+            hr += x.x * (double)w[j].x - x.y * (double)w[j].y;
+            hi += x.x * (double)w[j].y + x.y * (double)w[j].x;
+          }
         }
         H = mk<T>((T)hr, (T)hi);
       }
@@ -79,9 +87,18 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
     __syncthreads();
     const cx<T>* xf = xk + f * P.n_symb * (int64_t)nc;
     for (int s = 0; s < P.n_symb; ++s)
-      for (int k = gid; k < nc; k += 256) {
-        const int d = P.drole[k];
-        if (d >= 0) codes[s * nd + d] = (uint8_t)slice_symbol<T, BA>(tab, xf[(int64_t)s * nc + k] * geq[k]);
+      for (int k0 = gid; k0 < nc; k0 += 4 * 256) {                     // four carriers per thread in flight
+        cx<T> xv[4];
+        int dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 256 * u;
+          dv[u] = k < nc ? (int)P.drole[k] : -1;
+          xv[u] = dv[u] >= 0 ? xf[(int64_t)s * nc + k] : mk<T>(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (dv[u] >= 0) codes[s * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xv[u] * geq[k0 + 256 * u]);
       }
     __syncthreads();
     unsigned int err = 0;
