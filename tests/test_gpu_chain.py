@@ -308,3 +308,29 @@ def test_chain_full_size_properties(ofdm):
     assert torch.equal(out2["bits"], out["bits"][100:356])
     ber = errs.sum() / (F * data["bits"].shape[1])
     assert 0.02 < ber < 0.12
+
+
+def test_chain_plans_interleaved_and_growing_batches(ofdm, oracle):
+    """Workspaces are owned by the plan and grow on demand: two plans used alternately with growing / shrinking
+    batches (and one of them toggling MMSE mode) give the same per-frame results as a fresh single call."""
+    from ofdm_course_amd import frames as fr
+    cfg_a = fr.config_M()
+    cfg_b = fr.config_small(nfft=1024, n_carrier=256, comb=4, const="16QAM", n_symb=4, dominant_taps=3)
+    data_a = fr.make_frames(cfg_a, ofdm, 40, seed=21, precision="fp32")
+    data_b = fr.make_frames(cfg_b, ofdm, 40, seed=22, precision="fp32")
+    pa, pb = fr.make_plan(cfg_a, ofdm, precision="fp32"), fr.make_plan(cfg_b, ofdm, precision="fp32")
+    ref_a = np.asarray(ofdm.rx_chain_task5(fr.make_plan(cfg_a, ofdm, precision="fp32"), data_a["rx"],
+                                           ref_bits_packed=data_a["packed"])["errors"])
+    ref_b = np.asarray(ofdm.rx_chain_task5(fr.make_plan(cfg_b, ofdm, precision="fp32"), data_b["rx"],
+                                           ref_bits_packed=data_b["packed"])["errors"])
+    h, _ = ofdm.get_MP_channel_resp(cfg_b.taps, cfg_b.Nfft)
+    for n in (3, 17, 40, 5, 33):
+        ea = np.asarray(ofdm.rx_chain_task5(pa, np.asarray(data_a["rx"])[:, :n], ref_bits_packed=data_a["packed"][:n])["errors"])
+        eb = np.asarray(ofdm.rx_chain_task5(pb, np.asarray(data_b["rx"])[:, :n], ref_bits_packed=data_b["packed"][:n])["errors"])
+        assert np.array_equal(ea, ref_a[:n]) and np.array_equal(eb, ref_b[:n])
+        pb.set_mmse(np.asarray(h), 20.0)
+        em = np.asarray(ofdm.rx_chain_task5(pb, np.asarray(data_b["rx"])[:, :n], ref_bits_packed=data_b["packed"][:n])["errors"])
+        assert em.shape == (n,) and em.sum() > 0
+        pb.set_mmse(None)
+    out0 = ofdm.rx_chain_task5(pa, np.asarray(data_a["rx"])[:, :0])
+    assert np.asarray(out0["bits"]).shape[0] == 0
