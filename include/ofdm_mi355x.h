@@ -193,6 +193,15 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
  * values in the precision of `flags` (OFDM_F32 / OFDM_F64); h = NULL returns the plan to OMP mode.
  * Needs 2..512 pilots; the chain call needs the fast-path geometry (Nfft 512..4096). */
 int ofdm_rx_plan_set_mmse(ofdm_rx_plan* plan, const void* h, int64_t n_h, double snr_db, int flags);
+/* Synthetic RX frames of the plan's geometry, generated on the device (no host payload): per frame the TX + channel
+ * call order of T5/Main_model_Task_5.m:50-127 -- payload (one Philox4x32-10 draw per QAM symbol, stream = frame0 + f)
+ * -> mapping (T5/mapping.m) -> OFDM_map_carriers with the plan's pilot column on every symbol -> OFDM_modulator ->
+ * conv(x, h) truncated per frame (:126-127; h = host array of h_len complex taps in the precision of `flags`, NULL =
+ * no channel) -> Noise(snr_db) per frame (noise_on != 0).  rx_out: [frame_samples x n_frames]; ref_bits_out: packed
+ * payload bits [n_frames][frame_bytes] in the layout ofdm_rx_chain_task5 compares against; bits_out (optional): one
+ * byte per bit [n_frames][frame_bits].  Results depend on (seed, frame0 + f) only, not on how frames are batched. */
+int ofdm_tx_frames(ofdm_rx_plan* plan, const void* h, int h_len, double snr_db, int noise_on, uint64_t seed,
+                   int64_t frame0, int64_t n_frames, void* rx_out, uint8_t* ref_bits_out, uint8_t* bits_out, int flags);
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
 /* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
  * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call

@@ -616,6 +616,44 @@ class RxPlan:
         L.check(self.lib.ofdm_rx_plan_set_mmse(self.handle, hh.ctypes.data_as(C.c_void_p), hh.size, float(SNR),
                                                L.OFDM_F64 | L.OFDM_HOST), "rx_plan_set_mmse")
 
+    def tx_frames(self, n_frames, h=None, SNR=None, seed=1, frame0=0, device=None, want_bits=False):
+        """Synthetic RX frames of this plan's geometry generated on the device (ofdm_tx_frames): payload -> mapping ->
+        OFDM_map_carriers -> OFDM_modulator -> conv(h) -> Noise(SNR), the TX + channel call order of
+        T5/Main_model_Task_5.m:50-127 per frame.  h=None: no channel; SNR=None: no noise.
+        Returns dict(rx=[frame_samples, n_frames], packed=[n_frames, frame_bytes] (+ bits=[n_frames, frame_bits]));
+        torch CUDA tensors when `device` is given, numpy arrays otherwise."""
+        n_frames = int(n_frames)
+        cdt_np = np.complex128 if self.f64 else np.complex64
+        flags = (L.OFDM_F64 if self.f64 else L.OFDM_F32)
+        if device is not None:
+            dev = torch.device(device)
+            rx = torch.empty((n_frames, self.frame_samples), dtype=torch.complex128 if self.f64 else torch.complex64,
+                             device=dev)
+            packed = torch.empty((n_frames, self.frame_bytes), dtype=torch.uint8, device=dev)
+            bits = torch.empty((n_frames, self.frame_bits), dtype=torch.uint8, device=dev) if want_bits else None
+            L.check(self.lib.ofdm_set_stream(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "set_stream")
+            prx, ppk = C.c_void_p(rx.data_ptr()), C.c_void_p(packed.data_ptr())
+            pbt = C.c_void_p(bits.data_ptr()) if want_bits else None
+            flags |= L.OFDM_DEVICE
+        else:
+            L.check(self.lib.ofdm_set_stream(None), "set_stream")
+            rx = np.empty((n_frames, self.frame_samples), dtype=cdt_np)
+            packed = np.empty((n_frames, self.frame_bytes), dtype=np.uint8)
+            bits = np.empty((n_frames, self.frame_bits), dtype=np.uint8) if want_bits else None
+            prx, ppk = rx.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)
+            pbt = bits.ctypes.data_as(C.c_void_p) if want_bits else None
+        hh = None
+        if h is not None:
+            hh = np.ascontiguousarray(np.asarray(h.cpu().numpy() if _is_torch(h) else h).ravel().astype(cdt_np))
+        L.check(self.lib.ofdm_tx_frames(self.handle, hh.ctypes.data_as(C.c_void_p) if hh is not None else None,
+                                        0 if hh is None else hh.size, float(SNR if SNR is not None else 0.0),
+                                        int(SNR is not None), int(seed), int(frame0), n_frames, prx, ppk, pbt, flags),
+                "tx_frames")
+        out = dict(rx=rx.t() if device is not None else rx.T, packed=packed)
+        if want_bits:
+            out["bits"] = bits
+        return out
+
     def set_timing(self, enable=True):
         L.check(self.lib.ofdm_rx_plan_set_timing(self.handle, int(bool(enable))), "rx_plan_set_timing")
 

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "chain_fast_core.hpp"
+#include "rx_plan.hpp"
 
 namespace ofdm {
 
@@ -334,27 +335,6 @@ int chain_fast_run(const FastPlanView& pv, const void* tw, const void* rx, int64
                    const void* ref, void* errs, void* h_out, void* idx_out);
 }  // namespace ofdm
 
-struct ofdm_rx_plan {
-  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
-  int frame_words;
-  int pilots_in_band;
-  int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
-  void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
-  void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr, *ws_h = nullptr;
-  void* ws_x = nullptr;    // split path: X(1..N_carrier, :) of every symbol
-  int64_t ws_x_elems = 0;
-  void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
-  int m_pad = 0;
-  std::vector<int32_t> pilot_loc;      // 1-based, as given
-  int64_t ws_frames = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int timing = 0;          // ofdm_rx_plan_set_timing
-  int last_fast = 0;
-  int last_fused = 0;      // fast path ran rx_pilot_omp_kernel instead of rx_pilot_kernel + omp_batch_kernel
-  ConstellationInfo cinfo;
-  std::vector<c64> dict;
-};
-
 constexpr size_t GENERIC_LDS_LIMIT = 158 * 1024;
 // dynamic LDS the generic single kernel would ask for (mirrors chain_layout + launch_chain)
 static size_t generic_lds_bytes(const ofdm_rx_plan* pl) {
@@ -495,7 +475,8 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
 int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
-                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x};
+                  pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x,
+                  pl->ws_gen, pl->d_dict};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   delete pl;

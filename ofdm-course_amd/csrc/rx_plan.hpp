@@ -1,0 +1,30 @@
+// The RX plan object behind the opaque `ofdm_rx_plan*` of include/ofdm_mi355x.h (owned by ofdm_chain.hip; the frame
+// generator of ofdm_txgen.hip reads its geometry and tables).
+#pragma once
+#include <vector>
+
+#include "chain_fast_core.hpp"
+
+struct ofdm_rx_plan {
+  int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
+  int frame_words;
+  int pilots_in_band;
+  int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
+  void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
+  void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr, *ws_h = nullptr;
+  void* ws_x = nullptr;    // split path: X(1..N_carrier, :) of every symbol
+  int64_t ws_x_elems = 0;
+  void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
+  int m_pad = 0;
+  std::vector<int32_t> pilot_loc;      // 1-based, as given
+  int64_t ws_frames = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int timing = 0;          // ofdm_rx_plan_set_timing
+  int last_fast = 0;
+  int last_fused = 0;      // fast path ran rx_pilot_omp_kernel instead of rx_pilot_kernel + omp_batch_kernel
+  ofdm::ConstellationInfo cinfo;
+  std::vector<ofdm::c64> dict;
+  void* ws_gen = nullptr;  // ofdm_tx_frames: X / time-domain scratch for one chunk of frames
+  size_t ws_gen_bytes = 0;
+  void* d_dict = nullptr;  // constellation table in the plan's precision (ofdm_tx_frames)
+};

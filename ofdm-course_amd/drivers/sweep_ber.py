@@ -3,8 +3,9 @@ BASELINE config 5: Nfft 8192, 256-QAM, sparse 32-tap channel, OMP_estimate, 20 S
 
 The reference's sweeps are loops over independent SNR points (T5/Main_model_Task_5.m:303-346,
 T3/Main_model_Task_3.m:237-268).  Here every (snr_idx, batch_idx) tile is one unit: tiles are dealt round-robin
-to the ranks (`sweep.tiles_for_rank`), each tile generates its frames on its own GPU (TX -> multipath -> Noise,
-Philox streams keyed by the tile, so the table does not depend on the GPU count), runs `rx_chain_task5`, and adds
+to the ranks (`sweep.tiles_for_rank`), each tile generates its frames on its own GPU (`ofdm_tx_frames`: payload -> TX ->
+multipath -> Noise, Philox streams keyed by the tile, so the table does not depend on the GPU count; nothing is drawn
+or packed on the host), runs `rx_chain_task5`, and adds
 its error / bit counts.  One SUM all-reduce of the int64 counters ends the sweep -- no samples are exchanged.
 
     python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 4 --frames-per-tile 64
@@ -44,11 +45,11 @@ def run(config="C5", snrs=None, batches=2, frames_per_tile=32, precision="fp32",
     for si, bi in sweep.tiles_for_rank(len(snrs), batches, rank, world):
         cfg.SNR_dB = float(snrs[si])
         key, stream0 = sweep.tile_seed_stream(seed, si, bi, frames_per_tile)
-        data = fr.make_frames(cfg, ofdm, frames_per_tile, seed=key, precision=precision, device=dev, frame0=stream0)
+        data = fr.make_frames_device(cfg, ofdm, plan, frames_per_tile, seed=key, device=dev, frame0=stream0)
         if estimator == "mmse":
             plan.set_mmse(hh, cfg.SNR_dB)
-        out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=torch.from_numpy(data["packed"]).to(dev))
-        counters.add(si, 0, int(out["errors"].sum().item()), data["bits"].size)
+        out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"])
+        counters.add(si, 0, int(out["errors"].sum().item()), frames_per_tile * plan.frame_bits)
         n_tiles += 1
     torch.cuda.synchronize()
     local_s = time.perf_counter() - t0

@@ -153,3 +153,12 @@ def make_plan(cfg, api, precision="fp32", device=None):
     return api.RxPlan(cfg.Nfft, cfg.T_guard, cfg.N_symb, cfg.N_carrier, cfg.pilotCarriers, cfg.dataCarriers,
                       pilot_column(cfg, api), cfg.K, cfg.dominant_taps, cfg.Constellation, precision=precision,
                       device=device)
+
+
+def make_frames_device(cfg, api, plan, n_frames, seed=1, device=None, noise=True, frame0=0, want_bits=False):
+    """Same role as make_frames, generated entirely on the device by the plan (ofdm_tx_frames): no host payload, no host
+    packing -- what the sharded sweeps use.  The payload is the library's Philox draw (not make_frames' PCG64 bits), so the
+    two generators give different -- equally valid -- frames."""
+    h, _ = api.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+    return plan.tx_frames(n_frames, h=h, SNR=cfg.SNR_dB if noise else None, seed=seed, frame0=frame0, device=device,
+                          want_bits=want_bits)

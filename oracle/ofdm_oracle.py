@@ -773,3 +773,20 @@ def awgn_philox(n, seed, stream=0):
     u1 = (r[:, 1] + 0.5) * 2.0 ** -32
     rad = np.sqrt(-2.0 * np.log(u0))
     return rad * np.cos(2 * np.pi * u1), rad * np.sin(2 * np.pi * u1)
+
+
+def payload_codes_philox(n_symbols, bps, seed, stream=0):
+    """Payload draw of ofdm_tx_frames (csrc/ofdm_txgen.hip): QAM symbol j of a frame uses counter (j_lo, j_hi, stream, 1),
+    key = seed; its code is the top `bps` bits of word 0.  An INPUT convention of the build (the reference reads an image)."""
+    j = np.arange(int(n_symbols), dtype=np.uint64)
+    ctr = np.stack([j & np.uint64(0xFFFFFFFF), j >> np.uint64(32), np.full(j.size, stream, dtype=np.uint64),
+                    np.ones(j.size, dtype=np.uint64)], axis=1)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    return (philox4x32_10(ctr, key)[:, 0] >> np.uint32(32 - int(bps))).astype(np.int64)
+
+
+def payload_bits_philox(n_symbols, bps, seed, stream=0):
+    """The frame's bit vector for `payload_codes_philox`: MSB of each symbol first (mapping.m:15-18)."""
+    codes = payload_codes_philox(n_symbols, bps, seed, stream)
+    sh = np.arange(int(bps) - 1, -1, -1)
+    return ((codes[:, None] >> sh[None, :]) & 1).astype(np.uint8).ravel()
