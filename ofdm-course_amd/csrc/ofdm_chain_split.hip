@@ -2,7 +2,8 @@
 // (Nfft = 8192: BASELINE config "sparse 32-tap channel, OMP_estimate"; or a frame whose state does not fit the
 // single generic kernel's LDS).  Four stages, intermediates in HBM restricted to the carriers that are read:
 //
-//   demod_keep_kernel   OFDM_demodulator of every symbol, rows 1..N_carrier kept        (OFDM_demodulator.m:2-10)
+//   demod_keep8192_kernel / demod_keep_kernel
+//                       OFDM_demodulator of every symbol, rows 1..N_carrier kept        (OFDM_demodulator.m:2-10)
 //   pilot_ls_kernel     Y = X(pilotCarriers, 1) ./ pilotValues(:, 1)                    (Task5_part2.m:190)
 //   omp_batch_kernel    batch OMP with the MFMA dictionary correlation (ofdm_chain_fast.hip), or
 //   mmse_apply_*        the plan's MMSE operator (ofdm_chain_mmse.hip)
@@ -133,6 +134,96 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
   }
 }
 
+// OFDM_demodulator for Nfft = 8192 on the wave-local machinery of the fast path: one radix-2 decimation-in-frequency
+// step in registers,  even bins <- FFT4096(x[m] + x[m+4096]),  odd bins <- FFT4096((x[m] - x[m+4096]) W_8192^m),
+// then each half is an NW = 8 transform (radix-8 DIF exchange + one 512-point transform per wavefront, the last pass
+// pruned when only bins < 2048 are kept).  Persistent 512-thread workgroups; the kept rows are collected in LDS and
+// written out contiguously.
+template <typename T, bool PRUNE2>
+__global__ __launch_bounds__(512) void demod_keep8192_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ x,
+                                                             const cx<T>* __restrict__ tw4096, const cx<T>* __restrict__ tw8192,
+                                                             int64_t n_symb, int t_guard, int n_keep) {
+  constexpr int NW = 8;
+  constexpr int NOUT = PRUNE2 ? 2 : 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* lwv = (cx<T>*)smem;                                   // [NW][WAVE_LDS_ELEMS]; also the output staging
+  cx<T>* const ex = lwv;
+  cx<T>* twl = lwv + NW * WAVE_LDS_ELEMS;                      // [WAVE_TW_ELEMS]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
+  DifTw<T, NW> dt;
+  wave_tw_fill<T, NW>(twl, tw4096);
+  dif_tw_init<T, NW>(dt, gid, tw4096);
+  cx<T> twb[7], w2[8];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) twb[t - 1] = tw4096[(t * (lane & 7) * 8) * NW];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) w2[t] = tw8192[gid + 512 * t];
+  __syncthreads();
+  for (int64_t s = blockIdx.x; s < n_symb; s += gridDim.x) {
+    const cx<T>* src = y + s * (int64_t)(8192 + t_guard) + t_guard;
+    cx<T> a[8], b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a[t] = src[gid + 512 * t]; b[t] = src[gid + 512 * t + 4096]; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const cx<T> d = a[t] - b[t];
+      a[t] = a[t] + b[t];
+      b[t] = d * w2[t];
+    }
+    cx<T> oe[NOUT], oo[NOUT];
+    // even bins
+    dif_stage<T, NW>(a, dt);
+    __syncthreads();                                           // previous symbol's staged rows have been written out
+    dif_scatter<T, NW>(a, gid, ex);
+    __syncthreads();
+    dif_gather<T>(a, wave, lane, ex);
+    wave_fft512<T, PRUNE2>(a, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) oe[t] = a[t];
+    // odd bins
+    dif_stage<T, NW>(b, dt);
+    __syncthreads();
+    dif_scatter<T, NW>(b, gid, ex);
+    __syncthreads();
+    dif_gather<T>(b, wave, lane, ex);
+    wave_fft512<T, PRUNE2>(b, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) oo[t] = b[t];
+    __syncthreads();                                           // every wavefront is done with its private region
+    // bin k' = NW (lane + 64 t) + wave of each half  ->  rows 2k' (even) and 2k'+1 (odd); staged in 4608-row pieces
+    for (int base = 0; base < n_keep; base += NW * WAVE_LDS_ELEMS) {
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t) {
+        const int k = 2 * (NW * (lane + 64 * t) + wave) - base;
+        if (k >= 0 && k < NW * WAVE_LDS_ELEMS && k + base < n_keep) lwv[k] = oe[t];
+        if (k + 1 >= 0 && k + 1 < NW * WAVE_LDS_ELEMS && k + 1 + base < n_keep) lwv[k + 1] = oo[t];
+      }
+      __syncthreads();
+      cx<T>* dst = x + s * (int64_t)n_keep + base;
+      const int cnt = n_keep - base < NW * WAVE_LDS_ELEMS ? n_keep - base : NW * WAVE_LDS_ELEMS;
+      for (int i = gid; i < cnt; i += 512) dst[i] = lwv[i];
+      if (base + NW * WAVE_LDS_ELEMS < n_keep) __syncthreads();
+    }
+  }
+}
+
+template <typename T>
+static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guard, int n_keep) {
+  const void *tw4 = nullptr, *tw8 = nullptr;
+  OFDM_TRY(get_twiddles(4096, std::is_same<T, double>::value, &tw4));
+  OFDM_TRY(get_twiddles(8192, std::is_same<T, double>::value, &tw8));
+  const size_t dyn = sizeof(cx<T>) * ((size_t)8 * WAVE_LDS_ELEMS + WAVE_TW_ELEMS);
+  auto launch = [&](auto kern) -> int {
+    const int per_cu = resident_blocks_per_cu((const void*)kern, 512, dyn);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_symb, (int64_t)ctx().num_cu * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), dyn, ctx().stream, (const cx<T>*)y, (cx<T>*)x, (const cx<T>*)tw4,
+                       (const cx<T>*)tw8, n_symb, t_guard, n_keep);
+    return check_launch("demod_keep8192_kernel");
+  };
+  if (n_keep <= 2048) return launch(demod_keep8192_kernel<T, true>);
+  return launch(demod_keep8192_kernel<T, false>);
+}
+
 bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb, bool f64) {
   if (getenv("OFDM_CHAIN_GENERIC")) return false;
   if (taps > FAST_MAXT || bps > 8) return false;
@@ -158,7 +249,10 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   hipStream_t st = ctx().stream;
   if (pv.fused_out) *pv.fused_out = 0;
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
-  OFDM_TRY(demod_keep_device(rx, xk, pv.nfft, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, pv.f64 != 0));
+  if (pv.nfft == 8192 && !getenv("OFDM_SPLIT_GENERIC_FFT"))
+    OFDM_TRY(demod_keep8192_run<T>(rx, xk, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier));
+  else
+    OFDM_TRY(demod_keep_device(rx, xk, pv.nfft, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, pv.f64 != 0));
   hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
                      n_frames);
   OFDM_TRY(check_launch("pilot_ls_kernel"));
