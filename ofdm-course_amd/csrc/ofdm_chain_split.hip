@@ -59,47 +59,72 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
       if (index_out) index_out[f * taps + gid] = idx + 1;
     }
     __syncthreads();
-    for (int k = gid; k < nc; k += 256) {
-      cx<T> H;
-      if constexpr (HEXT) {
-        H = P.h_in[f * nc + k];
-      } else {
-        double hr = 0, hi = 0;
-        for (int q0 = 0; q0 < taps; q0 += 8) {                         // eight delays at a time: their twiddles in flight together
-          cx<T> w[8];
+    if constexpr (HEXT) {
+      for (int k = gid; k < nc; k += 256) {
+        const cx<T> H = P.h_in[f * nc + k];
+        if (h_out) h_out[f * nc + k] = H;
+        geq[k] = cdiv(mk<T>(1, 0), H);
+      }
+    } else {
+      // H(k) = sum_q x_q W^(idx_q k) for the thread's carriers k = base + gid + 256 u.  A table lookup per (carrier, tap)
+      // is a 64-address gather (stride idx_q) and made this stage gather-bound; instead ONE lookup per tap gives
+      // W^(idx_q (base + gid)) and the wavefront-uniform step W^(256 idx_q) carries it to the next carrier in double.
+      for (int base = 0; base < nc; base += 8 * 256) {
+        double hr[8], hi[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int idx = q0 + j < taps ? sh_tidx[q0 + j] : -1;
-            w[j] = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * k) & (nfft - 1))];
-          }
+        for (int u = 0; u < 8; ++u) hr[u] = hi[u] = 0;
+        for (int q = 0; q < taps; ++q) {
+          const int idx = sh_tidx[q];
+          if (idx < 0) continue;                                       // wavefront-uniform
+          const c64 x = sh_tx[q];
+          const cx<T> w0 = P.tw[(int)(((int64_t)idx * (base + gid)) & (nfft - 1))];
+          const cx<T> st = P.tw[(int)(((int64_t)idx * 256) & (nfft - 1))];
+          double wr = (double)w0.x, wi = (double)w0.y;
+          const double sr = (double)st.x, si = (double)st.y;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int q = q0 + j;
-            const c64 x = (q < taps && sh_tidx[q] >= 0) ? sh_tx[q] : c64{0, 0};   // zero for unused / overwritten slots
-            hr += x.x * (double)w[j].x - x.y * (double)w[j].y;
-            hi += x.x * (double)w[j].y + x.y * (double)w[j].x;
+          for (int u = 0; u < 8; ++u) {
+            hr[u] += x.x * wr - x.y * wi;
+            hi[u] += x.x * wi + x.y * wr;
+            const double nr = wr * sr - wi * si;
+            wi = wr * si + wi * sr;
+            wr = nr;
           }
         }
-        H = mk<T>((T)hr, (T)hi);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = base + gid + 256 * u;
+          if (k < nc) {
+            const cx<T> H = mk<T>((T)hr[u], (T)hi[u]);
+            if (h_out) h_out[f * nc + k] = H;
+            geq[k] = cdiv(mk<T>(1, 0), H);
+          }
+        }
       }
-      if (h_out) h_out[f * nc + k] = H;
-      geq[k] = cdiv(mk<T>(1, 0), H);
     }
     __syncthreads();
     const cx<T>* xf = xk + f * P.n_symb * (int64_t)nc;
-    for (int s = 0; s < P.n_symb; ++s)
-      for (int k0 = gid; k0 < nc; k0 += 4 * 256) {                     // four carriers per thread in flight
-        cx<T> xv[4];
-        int dv[4];
+    // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by
+    // the bytes it keeps in flight
+    for (int s0 = 0; s0 < P.n_symb; s0 += 2)
+      for (int k0 = gid; k0 < nc; k0 += 8 * 256) {
+        cx<T> xv[2][8];
+        int dv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int k = k0 + 256 * u;
           dv[u] = k < nc ? (int)P.drole[k] : -1;
-          xv[u] = dv[u] >= 0 ? xf[(int64_t)s * nc + k] : mk<T>(0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (dv[u] >= 0) codes[s * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xv[u] * geq[k0 + 256 * u]);
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? xf[(int64_t)(s0 + v) * nc + k0 + 256 * u] : mk<T>(0, 0);
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (dv[u] >= 0 && s0 + v < P.n_symb)
+              codes[(s0 + v) * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xv[v][u] * geq[k0 + 256 * u]);
       }
     __syncthreads();
     unsigned int err = 0;
@@ -264,7 +289,8 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
   const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
   auto launch = [&](auto kern) -> int {
-    const int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
+    int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
+    if (const char* e = getenv("OFDM_EQD_WG_PER_CU")) per_cu = std::max(1, atoi(e));
     const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), dyn, st, P, pv.nfft, (const cx<T>*)xk, n_frames, (uint32_t*)bits,
                        (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
