@@ -200,6 +200,7 @@ __device__ __forceinline__ void dif_gather(cx<T> (&v)[8], int wave, int lane, co
 template <typename T>
 struct FastParams {
   int n_symb, t_guard, n_carrier, np, nd, k_atoms, taps, frame_words, bps;
+  int comb_m;                // comb pilots 1 : comb : ... -> Nfft / comb (S^H Y is an inverse transform of that size), else 0
   const int16_t* prole;      // [nfft] pilot position of a carrier or -1
   const int16_t* drole;      // [nfft] data position of a carrier or -1
   const cx<T>* pilots;       // [np]
@@ -394,6 +395,7 @@ struct FastPlanView {
   int64_t* ws_frames;
   hipEvent_t* ev;          // 4 events bracketing the three launches when timing is enabled, else nullptr
   int comb_lg_up;          // comb pilots with (Nfft/comb) dividing 512: log2(512 / (Nfft/comb)); -1 otherwise
+  int comb_m;              // comb pilots: Nfft / comb, else 0
   int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
   const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
   int m_pad;

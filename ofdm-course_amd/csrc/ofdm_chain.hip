@@ -423,6 +423,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
     bool is_comb = comb >= 1 && nfft % comb == 0;
     for (int p = 0; p < n_pilots && is_comb; ++p) is_comb = pc0[p] == comb * p;
     const int m = is_comb ? nfft / comb : 0;
+    if (is_comb && n_pilots <= m) pl->comb_m = m;
     if (is_comb && m <= 512 && 512 % m == 0 && n_pilots <= m) {
       int lg = 0;
       while ((m << lg) < 512) ++lg;
@@ -580,6 +581,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     pv.ws_frames = &pl->ws_frames;
     pv.ev = pl->timing ? pl->ev : nullptr;
     pv.comb_lg_up = pl->comb_lg_up;
+    pv.comb_m = pl->comb_m;
     pv.fused_out = &pl->last_fused;
     pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
     pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;

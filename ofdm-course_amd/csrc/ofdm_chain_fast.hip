@@ -88,12 +88,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct OmpLayout {          // byte offsets into dynamic LDS
-  unsigned off_y, off_c0, off_gram, off_state, state_bytes, total;
+  unsigned off_y, off_c0, off_gram, off_state, off_fft, state_bytes, total;
   int fpw;                  // frames per wavefront
 };
 
 template <typename T>
-static OmpLayout omp_layout(int np, int k_atoms, int taps) {
+static OmpLayout omp_layout(int np, int k_atoms, int taps, int fft_elems = 0) {
   OmpLayout o;
   // per frame: R (taps*taps), z, x, l (taps each) complex T; picks (taps ints); ctl (n, stop) + rho (double)
   o.state_bytes = (unsigned)((sizeof(cx<T>) * ((size_t)taps * taps + 3 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
@@ -107,13 +107,19 @@ static OmpLayout omp_layout(int np, int k_atoms, int taps) {
   o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * fb * (np + 1) + 15) & ~15u);   // rows padded by one element
   o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * fb * k_atoms + 15) & ~15u);
   o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * k_atoms + 15) & ~15u);
-  o.off_state = b; b += fb * o.state_bytes;
+  // the transform scratch of the c0 stage is dead before the per-frame OMP state is first written: same bytes
+  const unsigned fft_bytes = (unsigned)((sizeof(cx<T>) * (size_t)fft_elems + 15) & ~15u);
+  o.off_state = b; o.off_fft = b;
+  b += std::max<unsigned>(fb * o.state_bytes, fft_bytes);
   o.total = b;
   return o;
 }
 
-template <typename T, bool MFMA>
-__global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayout lay, int64_t n_frames) {
+// CM = 2048: comb pilots with Nfft/comb = 2048 -- c0 = S^H Y is the first K outputs of a 2048-point inverse transform of
+// Y (one workgroup transform per frame, tw_m = its twiddle table) instead of the K x Np dictionary correlation.
+template <typename T, bool MFMA, int CM = 0>
+__global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayout lay, int64_t n_frames,
+                                                        const cx<T>* __restrict__ tw_m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* Yl = (cx<T>*)(smem + lay.off_y);       // [FB][np + 1]
   cx<T>* c0 = (cx<T>*)(smem + lay.off_c0);      // [FB][k_atoms]
@@ -131,7 +137,24 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
   for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
   __syncthreads();
   // ---- c0 = S^H Y
-  if constexpr (MFMA) {
+  if constexpr (CM > 0) {
+    static_assert(CM == 2048, "one 256-thread workgroup = one 2048-point transform");
+    cx<T>* fl = (cx<T>*)(smem + lay.off_fft);
+    for (int fi2 = 0; fi2 < FB; ++fi2) {
+      cx<T> v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = tid + e * (CM / 8);
+        v[e] = i < np ? conj(Yl[fi2 * YS + i]) : mk<T>(0, 0);
+      }
+      wg_fft<T, CM, false>(v, tid, tw_m, fl);                 // c0 = conj(FFT(conj(Y)))
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = tid + e * (CM / 8);
+        if (k < K) c0[fi2 * K + k] = conj(v[e]);
+      }
+    }
+  } else if constexpr (MFMA) {
     // real GEMM  C[K x 2 FB] = A[K x 2np] * B[2np x 2 FB]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
     // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
     // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 per 16x16 tile (real / imaginary parts of A).
@@ -245,15 +268,31 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     float bs = -1.0f;
     int bi = 0x7fffffff;
     if (active) {
-      for (int k = sl; k < K; k += LPF) {
-        cx<T> c = cf[k];
+      // eight atoms of the lane at a time: the picked index and its coefficient (group-uniform LDS reads) are fetched
+      // once per term and reused for the eight partial sums -- the stage is bound by its LDS reads
+      for (int kb = sl; kb < K; kb += 8 * LPF) {
+        cx<T> c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = kb + u * LPF < K ? cf[kb + u * LPF] : mk<T>(0, 0);
         for (int qq = 0; qq < n; ++qq) {
-          const int d = picks[qq] - k;
-          const cx<T> gv = gl[d >= 0 ? d : -d];
-          c = c - (d >= 0 ? gv : conj(gv)) * xv[qq];
+          const int pq = picks[qq];
+          const cx<T> xq = xv[qq];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int d = pq - (kb + u * LPF);
+            const int ad = d >= 0 ? d : -d;
+            const cx<T> gv = gl[ad < K ? ad : 0];
+            c[u] = c[u] - (d >= 0 ? gv : conj(gv)) * xq;
+          }
         }
-        const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
-        if (sc > bs) { bs = sc; bi = k; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb + u * LPF;
+          if (k < K) {
+            const float sc = (float)((double)c[u].x * c[u].x + (double)c[u].y * c[u].y);
+            if (sc > bs) { bs = sc; bi = k; }      // ascending k inside a lane: strict > keeps the first
+          }
+        }
       }
     }
     const float gmax = group_max_f(bs, LPF, lane);
@@ -491,6 +530,7 @@ int fast_params_prepare(const FastPlanView& pv, const void* tw, int64_t n_frames
   P.prole = (const int16_t*)pv.d_prole; P.drole = (const int16_t*)pv.d_drole;
   P.pilots = (const cx<T>*)pv.d_pilots; P.sct = (const cx<T>*)pv.d_sct; P.gram = (const c64*)pv.d_gram;
   P.tw = (const cx<T>*)tw;
+  P.comb_m = pv.comb_m;
   // workspace (grown on demand, kept by the plan)
   if (*pv.ws_frames < n_frames) {
     void** ptrs[] = {pv.ws_stash, pv.ws_ypil, pv.ws_tapidx, pv.ws_tapx, pv.ws_h};
@@ -520,18 +560,24 @@ template int fast_params_prepare<double>(const FastPlanView&, const void*, int64
 template <typename T>
 int omp_batch_run(const FastParams<T>& P, int64_t n_frames) {
   hipStream_t st = ctx().stream;
-  const OmpLayout lay = omp_layout<T>(P.np, P.k_atoms, P.taps);
+  const bool by_fft = P.comb_m == 2048 && P.np <= 2048 && P.k_atoms <= 2048 && !getenv("OFDM_OMP_NO_FFT");
+  const OmpLayout lay = omp_layout<T>(P.np, P.k_atoms, P.taps, by_fft ? fft_lds_elems(2048) : 0);
   OFDM_ARG(lay.total <= 150 * 1024, "rx_chain_task5: OMP stage needs %u bytes of LDS", lay.total);
   const unsigned grid = cdiv_u(n_frames, 4 * lay.fpw);
   const bool mfma = std::is_same<T, float>::value && (P.k_atoms % 16 == 0) && (P.np % 4 == 0) && !getenv("OFDM_OMP_NO_MFMA");
-  if (mfma) {
-    if constexpr (std::is_same<T, float>::value) {
-      OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-      hipLaunchKernelGGL((omp_batch_kernel<T, true>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
-    }
+  auto launch = [&](auto kern, const void* twm) -> int {
+    OFDM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lay.total, st, P, lay, n_frames, (const cx<T>*)twm);
+    return OFDM_OK;
+  };
+  if (by_fft) {
+    const void* twm = nullptr;
+    OFDM_TRY(get_twiddles(2048, std::is_same<T, double>::value, &twm));
+    OFDM_TRY(launch(omp_batch_kernel<T, false, 2048>, twm));
+  } else if (mfma) {
+    if constexpr (std::is_same<T, float>::value) OFDM_TRY(launch(omp_batch_kernel<T, true>, nullptr));
   } else {
-    OFDM_HIP(hipFuncSetAttribute((const void*)omp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-    hipLaunchKernelGGL((omp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, n_frames);
+    OFDM_TRY(launch(omp_batch_kernel<T, false>, nullptr));
   }
   return check_launch("omp_batch_kernel");
 }

@@ -9,6 +9,7 @@ struct ofdm_rx_plan {
   int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
   int frame_words;
   int pilots_in_band;
+  int comb_m = 0;          // comb pilots 1 : comb : ... -> Nfft / comb, else 0
   int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
   void *ws_stash = nullptr, *ws_ypil = nullptr, *ws_tapidx = nullptr, *ws_tapx = nullptr, *ws_h = nullptr;
