@@ -3,8 +3,8 @@
 Tg=256, N_carrier=512, comb 4, 64-QAM, OMP(6), frames of 14 symbols) on N MI355X GPUs.
 
 A "step" = one pass of the fused RX chain (ofdm_rx_chain_task5) over this rank's resident batch of
-synthetic frames (inputs already in HBM) + the end-of-tile SUM all-reduce of the error counters
-(RCCL, only when N > 1).  Weak scaling: every rank owns `--frames` frames; global frame ids (and
+synthetic frames (inputs already in HBM); the K timed steps end with the sweep's one SUM all-reduce of the
+error counters (RCCL, only when N > 1).  Weak scaling: every rank owns `--frames` frames; global frame ids (and
 therefore payload bits and noise) do not depend on the GPU count.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
@@ -105,11 +105,18 @@ def main():
     rx = data["rx"]
     torch.cuda.synchronize()
     frame_bits = data["bits"].shape[1]
-    counters = torch.zeros(2, dtype=torch.int64, device=cdev)
-
     def step():
         out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
         return out
+
+    def reduce_counters(last_out):
+        """The sweep's only collective: ONE SUM all-reduce of the int64 error / bit counters at its end
+        (every step decodes the same resident batch, so the last step's counters are the batch's)."""
+        c = torch.stack([last_out["errors"].sum().to(torch.int64),
+                         torch.tensor(F * frame_bits, dtype=torch.int64, device=dev)]).to(cdev)
+        if world > 1:
+            dist.all_reduce(c)
+        return c
 
     # one HIP event pair around the K timed steps, on the stream the library launches on (torch's current stream,
     # bound with ofdm_set_stream): a pair per step would put two barrier packets (~11 us) between steps
@@ -117,10 +124,7 @@ def main():
     out = None
     for _ in range(args.warmup):
         out = step()
-        if world > 1:
-            counters[0] = out["errors"].sum()
-            counters[1] = F * frame_bits
-            dist.all_reduce(counters)
+    reduce_counters(out)                       # warm the collective up as well
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,11 +132,8 @@ def main():
     ev[0].record()
     for i in range(args.steps):
         out = step()
-        if world > 1:
-            counters[0] = out["errors"].sum()
-            counters[1] = F * frame_bits
-            dist.all_reduce(counters)          # the sweep's only collective: SUM of the error / bit counters
     ev[1].record()
+    counters = reduce_counters(out)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -152,9 +153,6 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    if world == 1:
-        counters[0] = out["errors"].sum()
-        counters[1] = F * frame_bits
     tot_err, tot_bits = int(counters[0].item()), int(counters[1].item())
 
     if rank == 0:
