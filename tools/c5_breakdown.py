@@ -1,3 +1,4 @@
+"""Per-stage times of the split-form chain at the C5 geometry (Nfft 8192, 256-QAM) against the number of OMP taps."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
