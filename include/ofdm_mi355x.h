@@ -193,6 +193,23 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* plan);
  * values in the precision of `flags` (OFDM_F32 / OFDM_F64); h = NULL returns the plan to OMP mode.
  * Needs 2..512 pilots; the chain call needs the fast-path geometry (Nfft 512..4096). */
 int ofdm_rx_plan_set_mmse(ofdm_rx_plan* plan, const void* h, int64_t n_h, double snr_db, int flags);
+/* Task-4 receiver over a batch of frames, each frame one stream of N_symb guarded symbols (T4/Main_model_Task_4.m:278-347
+ * per frame, the plan supplying Nfft, T_guard, N_symb, the carrier sets, the pilot column and the constellation):
+ *   if time_desync || freq_desync:  AutoCorrFunction(Rx, T_guard, Nfft)                              (:278)
+ *   if time_desync:                 add_STO(Rx, TgPosition); add_STO(., -(Nfft+T_guard))             (:292-294)
+ *   if freq_desync:                 add_CFO(., -FreqOffset, Nfft); remove_IFO(., Nfft)               (:301-303)
+ *   OFDM_demodulator; fine_sync (Task-4 variant) if either flag                                      (:310-314)
+ *   if mp_desync:                   estimate_channel + equalize_signal                               (:318-334)
+ *   get_payload; demapping                                                                           (:340-347)
+ * bits_out: packed demapped bits per frame (layout of ofdm_rx_chain_task5; the per-frame DeScrambler of :354-364 is
+ * the caller's, ofdm_DeScrambler_frames); errors_out: differences to ref_bits (pass the scrambled bits).
+ * tg_position_out / freq_offset_out / ifo_out: the per-frame estimates (0 where a stage is off);
+ * status_out: 0 ok, 1 = AutoCorrFunction's catch branch (TgPosition 65, :19-24), -1 = remove_IFO found no line above
+ * 0.77 (the script would abort at remove_IFO.m:8; the frame is decoded with IFO = 0), -2 = TgPosition beyond AutoCorr.
+ * h_out (optional): H_est(1..N_carrier) per frame.  All arrays live where `flags` says.  At most 65535 frames per call. */
+int ofdm_rx_chain_task4(ofdm_rx_plan* plan, const void* rx, int64_t n_frames, int time_desync, int freq_desync, int mp_desync,
+                        uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out, int64_t* tg_position_out,
+                        double* freq_offset_out, int32_t* ifo_out, int32_t* status_out, void* h_out, int flags);
 /* Synthetic RX frames of the plan's geometry, generated on the device (no host payload): per frame the TX + channel
  * call order of T5/Main_model_Task_5.m:50-127 -- payload (one Philox4x32-10 draw per QAM symbol, stream = frame0 + f)
  * -> mapping (T5/mapping.m) -> OFDM_map_carriers with the plan's pilot column on every symbol -> OFDM_modulator ->

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ofdm_rx_plan_create": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _cp, _i],
     "ofdm_rx_plan_destroy": [_vp],
     "ofdm_rx_plan_set_mmse": [_vp, _vp, _i64, _d, _i],
+    "ofdm_rx_chain_task4": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ofdm_tx_frames": [_vp, _vp, _i, _d, _i, C.c_uint64, _i64, _i64, _vp, _vp, _vp, _i],
     "ofdm_rx_plan_frame_bytes": [_vp],
     "ofdm_rx_plan_set_timing": [_vp, _i],

@@ -35,7 +35,7 @@ __all__ = [
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
     "add_CFO", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
-    "MER_func", "RxPlan", "rx_chain_task5", "DEFAULT_REGISTER",
+    "MER_func", "RxPlan", "rx_chain_task5", "rx_chain_task4", "DEFAULT_REGISTER",
 ]
 
 DEFAULT_REGISTER = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)   # T5/Main_model_Task_5.m:55
@@ -701,3 +701,36 @@ def rx_chain_task5(plan: RxPlan, rx, ref_bits_packed=None, want_h=False, want_in
     L.check(call.lib.ofdm_rx_chain_task5(plan.handle, call.cin(rx), nfr, pbits, pref, perr, pH, pidx, call.flags),
             "rx_chain_task5")
     return dict(bits=bits, errors=errors, H=H, index=idx)
+
+
+def rx_chain_task4(plan: RxPlan, rx, time_desync=1, freq_desync=1, mp_desync=1, ref_bits_packed=None, want_h=False):
+    """Task-4 receiver over a batch of frames (T4/Main_model_Task_4.m:278-347 per frame): AutoCorrFunction -> add_STO x2 ->
+    add_CFO -> remove_IFO -> OFDM_demodulator -> fine_sync -> estimate_channel -> equalize_signal -> get_payload -> demapping.
+
+    rx: [(Nfft+Tg)*N_symb, n_frames] complex (numpy -> host flavour, torch.cuda -> device flavour).
+    Returns dict(bits=[n_frames, frame_bytes] packed demapped bits (not descrambled), errors vs ref_bits_packed or None,
+    TgPosition=[n_frames] int64, FreqOffset=[n_frames] float64, IFO=[n_frames] int32, status=[n_frames] int32
+    (0 ok, 1 AutoCorrFunction fallback, -1 no IFO line, -2 TgPosition out of range), H=[N_carrier, n_frames] or None)."""
+    call = _Call(rx, f64=plan.f64)
+    rows, nfr = _shape2(rx)
+    if rows != plan.frame_samples:
+        raise OfdmError("rx_chain_task4: rx must have (Nfft+T_guard)*N_symb rows")
+    flat_bits, pbits = call._out((plan.frame_bytes * nfr,), np.uint8, torch.uint8 if call.dev else None)
+    bits = flat_bits.reshape(nfr, plan.frame_bytes)
+    pref, errors, perr = None, None, None
+    if ref_bits_packed is not None:
+        ref = ref_bits_packed
+        if tuple(ref.shape) != (nfr, plan.frame_bytes):
+            raise OfdmError("rx_chain_task4: ref_bits_packed must be [n_frames, frame_bytes]")
+        ref = ref.contiguous().view(-1) if _is_torch(ref) else np.ascontiguousarray(ref).reshape(-1)
+        pref = call._flat(ref, np.uint8, torch.uint8 if call.dev else None)[0]
+        errors, perr = call._out((nfr,), np.uint32, torch.int32 if call.dev else None)
+    tg, ptg = call._out((nfr,), np.int64, torch.int64 if call.dev else None)
+    fo, pfo = call._out((nfr,), np.float64, torch.float64 if call.dev else None)
+    ifo, pifo = call._out((nfr,), np.int32, torch.int32 if call.dev else None)
+    stt, pst = call._out((nfr,), np.int32, torch.int32 if call.dev else None)
+    H, pH = (call.cout((plan.N_carrier, nfr)) if want_h else (None, None))
+    L.check(call.lib.ofdm_rx_chain_task4(plan.handle, call.cin(rx), nfr, int(bool(time_desync)), int(bool(freq_desync)),
+                                         int(bool(mp_desync)), pbits, pref, perr, ptg, pfo, pifo, pst, pH, call.flags),
+            "rx_chain_task4")
+    return dict(bits=bits, errors=errors, TgPosition=tg, FreqOffset=fo, IFO=ifo, status=stt, H=H)

@@ -572,19 +572,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
     split = pl->nfft > 4096 || pl->d_wt != nullptr || generic_lds_bytes(pl) > GENERIC_LDS_LIMIT;
   if (fast || split) {
     FastPlanView pv;
-    pv.nfft = pl->nfft; pv.t_guard = pl->t_guard; pv.n_symb = pl->n_symb; pv.n_carrier = pl->n_carrier;
-    pv.np = pl->np; pv.nd = pl->nd; pv.k_atoms = pl->k_atoms; pv.taps = pl->taps; pv.bps = pl->bps;
-    pv.f64 = pl->f64; pv.frame_words = pl->frame_words;
-    pv.d_prole = pl->d_prole; pv.d_drole = pl->d_drole; pv.d_pilots = pl->d_pilots; pv.d_sct = pl->d_sct;
-    pv.d_gram = pl->d_gram; pv.dict = &pl->dict; pv.cinfo = &pl->cinfo;
-    pv.ws_stash = &pl->ws_stash; pv.ws_ypil = &pl->ws_ypil; pv.ws_tapidx = &pl->ws_tapidx; pv.ws_tapx = &pl->ws_tapx;
-    pv.ws_frames = &pl->ws_frames;
-    pv.ev = pl->timing ? pl->ev : nullptr;
-    pv.comb_lg_up = pl->comb_lg_up;
-    pv.comb_m = pl->comb_m;
-    pv.fused_out = &pl->last_fused;
-    pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
-    pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
+    make_plan_view(pl, pv);
     pl->last_fast = 1;
     if (fast) OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
     else OFDM_TRY(chain_split_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx, (const int32_t*)pl->d_pc0));

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void pilot_ls_kernel(FastParams<T> P, const cx
 // one workgroup per frame (grid-stride): G = 1 ./ H in LDS, then every symbol's data carriers
 template <typename T, int BA, bool HEXT>
 __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft, const cx<T>* __restrict__ xk,
-                                                       int64_t n_frames, uint32_t* __restrict__ bits_out,
+                                                       int x_stride /* rows per symbol column of xk */, int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                        const uint32_t* __restrict__ ref_bits,
                                                        uint32_t* __restrict__ errors_out, cx<T>* __restrict__ h_out,
                                                        int32_t* __restrict__ index_out, DemapTable<T> tab) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
       }
     }
     __syncthreads();
-    const cx<T>* xf = xk + f * P.n_symb * (int64_t)nc;
+    const cx<T>* xf = xk + f * P.n_symb * (int64_t)x_stride;
     // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by
     // the bytes it keeps in flight
     for (int s0 = 0; s0 < P.n_symb; s0 += 2)
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
         for (int v = 0; v < 2; ++v)
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? xf[(int64_t)(s0 + v) * nc + k0 + 256 * u] : mk<T>(0, 0);
+            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? xf[(int64_t)(s0 + v) * x_stride + k0 + 256 * u] : mk<T>(0, 0);
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -257,6 +257,40 @@ bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t n
   return lds <= 120 * 1024;
 }
 
+// equalise + demap + pack + BER of n_frames frames from X columns of x_stride rows (rows 1..N_carrier are read)
+template <typename T>
+int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk, int x_stride, bool hext, int64_t n_frames,
+                 void* bits, const void* ref, void* errs, void* h_out, void* idx_out) {
+  hipStream_t st = ctx().stream;
+  DemapTable<T> tab;
+  fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
+  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+  OFDM_ARG(dyn <= 150 * 1024, "rx_chain: equalise / demap stage needs %zu bytes of LDS", dyn);
+  auto launch = [&](auto kern) -> int {
+    int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
+    if (const char* e = getenv("OFDM_EQD_WG_PER_CU")) per_cu = std::max(1, atoi(e));
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), dyn, st, P, pv.nfft, xk, x_stride, n_frames, (uint32_t*)bits,
+                       (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
+    return OFDM_OK;
+  };
+  const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
+#define SPLIT_CASE(BAV)                                                                                    \
+  if (hext) OFDM_TRY(launch(eq_demap_kernel<T, BAV, true>)); else OFDM_TRY(launch(eq_demap_kernel<T, BAV, false>))
+  switch (ba) {
+    case 2: SPLIT_CASE(2); break;
+    case 3: SPLIT_CASE(3); break;
+    case 4: SPLIT_CASE(4); break;
+    default: SPLIT_CASE(0); break;
+  }
+#undef SPLIT_CASE
+  return check_launch("eq_demap_kernel");
+}
+template int eq_demap_run<float>(const FastPlanView&, const FastParams<float>&, const cx<float>*, int, bool, int64_t, void*,
+                                 const void*, void*, void*, void*);
+template int eq_demap_run<double>(const FastPlanView&, const FastParams<double>&, const cx<double>*, int, bool, int64_t, void*,
+                                  const void*, void*, void*, void*);
+
 template <typename T>
 static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
                      const void* ref, void* errs, void* h_out, void* idx_out, const int32_t* d_pc0) {
@@ -285,28 +319,7 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   if (mmse) OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
   else OFDM_TRY(omp_batch_run<T>(P, n_frames));
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
-  DemapTable<T> tab;
-  fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
-  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
-  auto launch = [&](auto kern) -> int {
-    int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
-    if (const char* e = getenv("OFDM_EQD_WG_PER_CU")) per_cu = std::max(1, atoi(e));
-    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), dyn, st, P, pv.nfft, (const cx<T>*)xk, n_frames, (uint32_t*)bits,
-                       (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
-    return OFDM_OK;
-  };
-  const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
-#define SPLIT_CASE(BAV)                                                                                    \
-  if (mmse) OFDM_TRY(launch(eq_demap_kernel<T, BAV, true>)); else OFDM_TRY(launch(eq_demap_kernel<T, BAV, false>))
-  switch (ba) {
-    case 2: SPLIT_CASE(2); break;
-    case 3: SPLIT_CASE(3); break;
-    case 4: SPLIT_CASE(4); break;
-    default: SPLIT_CASE(0); break;
-  }
-#undef SPLIT_CASE
-  OFDM_TRY(check_launch("eq_demap_kernel"));
+  OFDM_TRY(eq_demap_run<T>(pv, P, xk, pv.n_carrier, mmse, n_frames, bits, ref, errs, h_out, idx_out));
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
   return OFDM_OK;
 }

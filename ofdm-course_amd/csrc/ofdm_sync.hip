@@ -1,6 +1,9 @@
 // Receiver synchronisation: AutoCorrFunction (sliding CP autocorrelation + plateau search),
 // remove_IFO, fine_sync.
-#include "ofdm_common.hpp"
+#include <algorithm>
+
+#include "rx_plan.hpp"
+#include "spline_op.hpp"
 
 namespace ofdm {
 
@@ -37,6 +40,8 @@ __device__ __forceinline__ acf4 acf_shfl_up(acf4 v, int d) {
 template <typename T>
 __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
                                                           cx<T>* __restrict__ rho, int64_t n_out) {
+  x += (int64_t)blockIdx.y * len;                    // grid.y = frame (one stream per frame, batched callers)
+  rho += (int64_t)blockIdx.y * n_out;
   __shared__ acf4 S[ACF_ELEMS + 1];                  // exclusive prefix: S[i] = sum_{m<i}
   __shared__ acf4 wtot[ACF_THREADS / 64];
   __shared__ acf4 carry_s;
@@ -110,6 +115,9 @@ template <typename T>
 __global__ __launch_bounds__(PLAT_THREADS) void acf_plateau_kernel(const cx<T>* __restrict__ rho, int64_t n, int W,
                                                                    double thr, int64_t* __restrict__ out,
                                                                    double* __restrict__ outv) {
+  rho += (int64_t)blockIdx.x * n;                    // grid.x = frame
+  out += 2 * blockIdx.x;
+  outv += 2 * blockIdx.x;
   __shared__ int64_t sh;
   auto above = [thr](cx<T> v) { return sqrt((double)v.x * v.x + (double)v.y * v.y) > thr; };
   auto below = [thr](cx<T> v) { return !(sqrt((double)v.x * v.x + (double)v.y * v.y) > thr); };
@@ -139,6 +147,8 @@ __global__ __launch_bounds__(PLAT_THREADS) void acf_plateau_kernel(const cx<T>* 
 template <typename T>
 __global__ __launch_bounds__(PLAT_THREADS) void first_above_kernel(const cx<T>* __restrict__ spec, int64_t n, double thr,
                                                                    int64_t* __restrict__ out) {
+  spec += (int64_t)blockIdx.x * n;                   // grid.x = frame
+  out += blockIdx.x;
   __shared__ int64_t sh;
   auto above = [thr](cx<T> v) { return sqrt((double)v.x * v.x + (double)v.y * v.y) > thr; };
   const int64_t f = first_index_where<T>(spec, 0, n, above, &sh);
@@ -162,6 +172,7 @@ struct PilotView {
   const int32_t* pc0;       // 0-based pilot rows
   int nfft, np;
   int64_t M;
+  int64_t rx_fstride;       // elements between the frames of a batch (0 for a single frame)
   __device__ void q(int64_t i, double& qr, double& qi) const {     // q = tx * conj(rx)
     const int p = (int)(i % np);
     const int64_t s = i / np;
@@ -183,6 +194,8 @@ struct PilotView {
 template <typename T>
 __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, double deltak, int variant,
                                                               double* __restrict__ out /* [0]=tau */) {
+  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
+  out += 2 * blockIdx.x;
   __shared__ int wcnt[FS_THREADS / 64];
   __shared__ double wsum[FS_THREADS / 64];
   __shared__ int64_t wn[FS_THREADS / 64];
@@ -226,6 +239,8 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
 template <typename T>
 __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv, int time_desync,
                                                                 double* __restrict__ out) {
+  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
+  out += 2 * blockIdx.x;
   __shared__ double wsum[FS_THREADS / 64];
   __shared__ int64_t wn[FS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -261,6 +276,9 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
 template <typename T>
 __global__ void fine_apply_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict__ y, int nfft, int64_t n_symb,
                                   int time_desync, int freq_desync, const double* __restrict__ est) {
+  x += (int64_t)blockIdx.y * nfft * n_symb;          // grid.y = frame
+  y += (int64_t)blockIdx.y * nfft * n_symb;
+  est += 2 * blockIdx.y;
   const double tau = est[0], ph = est[1];
   double psn = 0.0, pcs = 1.0;
   if (freq_desync) sincos(ph, &psn, &pcs);
@@ -279,11 +297,256 @@ __global__ void fine_apply_kernel(const cx<T>* __restrict__ x, cx<T>* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Task-4 receiver for a batch of frames (ofdm_rx_chain_task4): every stage above with grid.x / grid.y = frame, the
+// per-frame scalars (TgPosition, FreqOffset, IFO, fine-sync estimates) never leave the device.
+// ---------------------------------------------------------------------------------------------
+// plateau result -> TgPosition, FreqOffset = -angle(rho(TgPosition)) / (2 pi) (AutoCorrFunction.m:27), status
+__global__ void t4_scalars_kernel(const int64_t* __restrict__ res, const double* __restrict__ resv, int64_t n_out,
+                                  int64_t* __restrict__ tg, double* __restrict__ fo, int32_t* __restrict__ status,
+                                  int64_t n_frames) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const int64_t pos = res[2 * f];
+  tg[f] = pos;
+  fo[f] = -atan2(resv[2 * f + 1], resv[2 * f]) / (2.0 * M_PI);
+  status[f] = pos > n_out ? -2 : (res[2 * f + 1] ? 0 : 1);     // -2: index error at :27, 1: catch branch (65)
+}
+
+// add_STO(rx, TgPosition), add_STO(., -(Nfft+Tg)) (T4/Main_model_Task_4.m:292-294) and add_CFO(., -FreqOffset) (:301) in
+// one pass: the shifts are copies, the rotation is the arithmetic of cfo_kernel.
+template <typename T>
+__global__ void t4_align_kernel(const cx<T>* __restrict__ rx, cx<T>* __restrict__ y, int64_t len, int sym_len, int nfft,
+                                int time_desync, int freq_desync, const int64_t* __restrict__ tg,
+                                const double* __restrict__ fo) {
+  const int64_t f = blockIdx.y;
+  const cx<T>* x = rx + f * len;
+  cx<T>* o = y + f * len;
+  const int64_t pos = time_desync ? tg[f] : 0;
+  const double cfo = freq_desync ? -fo[f] : 0.0;
+  const double inv_nfft = 1.0 / (double)nfft;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    cx<T> v = mk<T>(0, 0);
+    if (time_desync) {
+      const int64_t i1 = i - sym_len;                              // index in add_STO(rx, pos)
+      if (i1 >= 0 && i1 < len - pos && i1 + pos < len) v = x[i1 + pos];
+    } else {
+      v = x[i];
+    }
+    if (freq_desync) {
+      const double t = cfo * (double)i * inv_nfft;
+      const double fr = t - floor(t);
+      double sn, cs;
+      sincospi(2.0 * fr, &sn, &cs);
+      v = mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
+    }
+    o[i] = v;
+  }
+}
+
+// rx_signal(Nfft+1 : 2*Nfft) of every frame, contiguous (remove_IFO.m:5)
+template <typename T>
+__global__ void t4_segment_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ seg, int64_t len, int nfft) {
+  const int64_t f = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nfft; k += gridDim.x * blockDim.x)
+    seg[f * nfft + k] = y[f * len + nfft + k];
+}
+
+// add_CFO(., -IFO) in place (remove_IFO.m:9); frames without a line above 0.77 are marked (MATLAB would abort)
+template <typename T>
+__global__ void t4_ifo_kernel(cx<T>* __restrict__ y, int64_t len, int nfft, const int64_t* __restrict__ first,
+                              int32_t* __restrict__ ifo_out, int32_t* __restrict__ status) {
+  const int64_t f = blockIdx.y;
+  const int64_t fi = first[f];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ifo_out[f] = (int32_t)fi;
+    if (fi < 0 && status[f] >= 0) status[f] = -1;
+  }
+  if (fi <= 0) return;                                             // nothing to rotate
+  const double cfo = -(double)fi, inv_nfft = 1.0 / (double)nfft;
+  cx<T>* o = y + f * len;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const double t = cfo * (double)i * inv_nfft;
+    const double fr = t - floor(t);
+    double sn, cs;
+    sincospi(2.0 * fr, &sn, &cs);
+    const cx<T> v = o[i];
+    o[i] = mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
+  }
+}
+
+// estimate_channel.m:6 per frame, then the spline operator of :8 restricted to rows 1..N_carrier (what equalize_signal reads)
+template <typename T>
+__global__ void t4_mean_pilots_kernel(const cx<T>* __restrict__ X, const cx<T>* __restrict__ tx, const int32_t* __restrict__ pc0,
+                                      cx<T>* __restrict__ hp, int nfft, int np, int n_symb) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  if (p >= np) return;
+  const cx<T>* rx = X + f * (int64_t)nfft * n_symb;
+  double ar = 0, ai = 0;
+  for (int s = 0; s < n_symb; ++s) {
+    const cx<T> q = cdiv(rx[(int64_t)s * nfft + pc0[p]], tx[s * np + p]);
+    ar += (double)q.x;
+    ai += (double)q.y;
+  }
+  hp[f * np + p] = mk<T>((T)(ar / (double)n_symb), (T)(ai / (double)n_symb));
+}
+
+template <typename T>
+__global__ void t4_apply_operator_kernel(const T* __restrict__ W, const cx<T>* __restrict__ hp, cx<T>* __restrict__ hout,
+                                         int n_out, int n_in) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  if (m >= n_out) return;
+  double ar = 0, ai = 0;                                           // double: the not-a-knot weights alternate in sign
+  for (int j = 0; j < n_in; ++j) {
+    const double w = (double)W[(size_t)j * n_out + m];
+    const cx<T> z = hp[f * n_in + j];
+    ar += w * (double)z.x;
+    ai += w * (double)z.y;
+  }
+  hout[f * n_out + m] = mk<T>((T)ar, (T)ai);
+}
+
+template <typename T>
+__global__ void t4_fill_ones_kernel(cx<T>* __restrict__ h, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) h[i] = mk<T>(1, 0);
+}
+
+template <typename T>
+static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desync, int freq_desync, int mp_desync,
+                     void* dbits, const void* dref, void* derr, int64_t* dtg, double* dfo, int32_t* difo, int32_t* dstat,
+                     void* dh_out, Stage& st) {
+  const int N = pl->nfft, Tg = pl->t_guard, S = pl->n_symb, np = pl->np, nc = pl->n_carrier;
+  const int64_t len = (int64_t)(N + Tg) * S;
+  const int64_t n_out = len - Tg - N;
+  const bool f64 = std::is_same<T, double>::value;
+  hipStream_t s = ctx().stream;
+  const bool sync = time_desync || freq_desync;
+  void *drho = nullptr, *dres, *dresv, *dy, *dseg, *dspec, *dfirst, *dX, *dest, *dhp, *dH;
+  OFDM_TRY(st.scratch(sizeof(int64_t) * 2 * F, &dres));
+  OFDM_TRY(st.scratch(sizeof(double) * 2 * F, &dresv));
+  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)len * F, &dy));
+  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * S * F, &dX));
+  OFDM_TRY(st.scratch(sizeof(double) * 2 * F, &dest));
+  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)np * F, &dhp));
+  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)nc * F, &dH));
+  OFDM_HIP(hipMemsetAsync(dstat, 0, sizeof(int32_t) * F, s));
+  OFDM_HIP(hipMemsetAsync(dtg, 0, sizeof(int64_t) * F, s));
+  OFDM_HIP(hipMemsetAsync(dfo, 0, sizeof(double) * F, s));
+  OFDM_HIP(hipMemsetAsync(difo, 0, sizeof(int32_t) * F, s));
+  if (sync) {
+    OFDM_ARG(n_out > 0 && Tg >= 1 && Tg <= ACF_MAXW, "rx_chain_task4: frame shorter than T_guard + Nfft, or T_guard outside 1..%d", ACF_MAXW);
+    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)n_out * F, &drho));
+    hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
+                       N, (cx<T>*)drho, n_out);
+    hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
+                       (int64_t*)dres, (double*)dresv);
+    hipLaunchKernelGGL(t4_scalars_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, (const double*)dresv, n_out,
+                       dtg, dfo, dstat, F);
+    OFDM_TRY(check_launch("AutoCorrFunction stage"));
+  }
+  const unsigned gl = (unsigned)std::min<int64_t>((len + 255) / 256, 64);
+  hipLaunchKernelGGL(t4_align_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dy, len, N + Tg, N,
+                     sync ? time_desync : 0, sync ? freq_desync : 0, (const int64_t*)dtg, (const double*)dfo);
+  OFDM_TRY(check_launch("t4_align_kernel"));
+  if (freq_desync) {
+    OFDM_ARG(len >= 2 * (int64_t)N, "rx_chain_task4: rx_signal(Nfft+1:2*Nfft) exceeds the frame");
+    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * F, &dseg));
+    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * F, &dspec));
+    OFDM_TRY(st.scratch(sizeof(int64_t) * F, &dfirst));
+    hipLaunchKernelGGL(t4_segment_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)dy, (cx<T>*)dseg, len, N);
+    OFDM_TRY(demod_device(dseg, dspec, N, F, 0, f64));
+    hipLaunchKernelGGL(first_above_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)dspec, (int64_t)N, 0.77,
+                       (int64_t*)dfirst);
+    hipLaunchKernelGGL(t4_ifo_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (cx<T>*)dy, len, N, (const int64_t*)dfirst, difo, dstat);
+    OFDM_TRY(check_launch("remove_IFO stage"));
+  }
+  OFDM_TRY(demod_device(dy, dX, N, (int64_t)S * F, Tg, f64));                       // T4:308-310
+  // pilot matrix [np x S] = the plan's pilot column on every symbol (T4:28-31)
+  std::vector<cx<T>> col(np), txm((size_t)np * S);
+  OFDM_HIP(hipMemcpyAsync(col.data(), pl->d_pilots, sizeof(cx<T>) * np, hipMemcpyDeviceToHost, s));
+  OFDM_HIP(hipStreamSynchronize(s));
+  for (int sy = 0; sy < S; ++sy) std::copy(col.begin(), col.end(), txm.begin() + (size_t)sy * np);
+  const void *dtx, *dW;
+  OFDM_TRY(st.upload(txm.data(), sizeof(cx<T>) * txm.size(), &dtx));
+  if (sync) {
+    OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
+    const double deltak = (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0];       // fine_sync.m:6
+    PilotView<T> pv{(const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, N, np, (int64_t)np * S, (int64_t)N * S};
+    hipLaunchKernelGGL(fine_tau_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, deltak, 1 /* T4 variant */, (double*)dest);
+    hipLaunchKernelGGL(fine_phase_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, time_desync, (double*)dest);
+    hipLaunchKernelGGL(fine_apply_kernel<T>, dim3(64, (unsigned)F), dim3(256), 0, s, (const cx<T>*)dX, (cx<T>*)dX, N, (int64_t)S,
+                       time_desync, freq_desync, (const double*)dest);
+    OFDM_TRY(check_launch("fine_sync stage"));
+  }
+  if (mp_desync) {
+    std::vector<double> xk(np), xq(nc), W;
+    for (int i = 0; i < np; ++i) xk[i] = pl->pilot_loc[i];
+    for (int i = 0; i < nc; ++i) xq[i] = i + 1.0;
+    OFDM_TRY(build_spline_operator(xk, xq, W));                                       // estimate_channel.m:8, rows 1..N_carrier
+    std::vector<T> Wt(W.begin(), W.end());
+    OFDM_TRY(st.upload(Wt.data(), sizeof(T) * Wt.size(), &dW));
+    hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s, (const cx<T>*)dX, (const cx<T>*)dtx,
+                       (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S);
+    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), (unsigned)F), dim3(128), 0, s, (const T*)dW, (const cx<T>*)dhp,
+                       (cx<T>*)dH, nc, np);
+  } else {
+    hipLaunchKernelGGL(t4_fill_ones_kernel<T>, dim3(256), dim3(256), 0, s, (cx<T>*)dH, (int64_t)nc * F);
+  }
+  OFDM_TRY(check_launch("estimate_channel stage"));
+  FastPlanView pv2;
+  make_plan_view(pl, pv2);
+  pv2.ev = nullptr;
+  FastParams<T> P;
+  const void* tw = nullptr;
+  OFDM_TRY(get_twiddles(N, f64, &tw));
+  OFDM_TRY(fast_params_prepare<T>(pv2, tw, F, P));
+  P.h_in = (const cx<T>*)dH;
+  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, N, true, F, dbits, dref, derr, dh_out, nullptr));   // T4:334-347
+  return OFDM_OK;
+}
+
 }  // namespace ofdm
 
 using namespace ofdm;
 
 extern "C" {
+
+int ofdm_rx_chain_task4(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, int time_desync, int freq_desync, int mp_desync,
+                        uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out, int64_t* tg_position_out,
+                        double* freq_offset_out, int32_t* ifo_out, int32_t* status_out, void* h_out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(pl && rx && n_frames >= 0, "rx_chain_task4: bad arguments");
+  OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "rx_chain_task4: precision flag differs from the plan's");
+  OFDM_ARG(pl->pilots_in_band, "rx_chain_task4: pilots outside 1..N_carrier are not supported");
+  OFDM_ARG(!errors_out || ref_bits, "rx_chain_task4: errors_out needs ref_bits");
+  OFDM_ARG(n_frames <= 65535, "rx_chain_task4: at most 65535 frames per call");
+  if (n_frames == 0) return OFDM_OK;
+  const size_t cs = csize(flags);
+  const size_t frame_samples = (size_t)(pl->nfft + pl->t_guard) * pl->n_symb;
+  const size_t fb = (size_t)pl->frame_words * 4;
+  Stage st(flags);
+  const void *drx, *dref; void *dbits, *derr, *dtg, *dfo, *difo, *dstat, *dh;
+  OFDM_TRY(st.in(rx, cs * frame_samples * n_frames, &drx));
+  OFDM_TRY(st.in(ref_bits, fb * n_frames, &dref));
+  OFDM_TRY(st.out(bits_out, fb * n_frames, &dbits));
+  OFDM_TRY(st.out(errors_out, sizeof(uint32_t) * n_frames, &derr));
+  OFDM_TRY(st.out(h_out, cs * (size_t)pl->n_carrier * n_frames, &dh));
+  // the per-frame scalars are always produced (scratch when the caller does not want them)
+  if (tg_position_out) OFDM_TRY(st.out(tg_position_out, sizeof(int64_t) * n_frames, &dtg)); else OFDM_TRY(st.scratch(sizeof(int64_t) * n_frames, &dtg));
+  if (freq_offset_out) OFDM_TRY(st.out(freq_offset_out, sizeof(double) * n_frames, &dfo)); else OFDM_TRY(st.scratch(sizeof(double) * n_frames, &dfo));
+  if (ifo_out) OFDM_TRY(st.out(ifo_out, sizeof(int32_t) * n_frames, &difo)); else OFDM_TRY(st.scratch(sizeof(int32_t) * n_frames, &difo));
+  if (status_out) OFDM_TRY(st.out(status_out, sizeof(int32_t) * n_frames, &dstat)); else OFDM_TRY(st.scratch(sizeof(int32_t) * n_frames, &dstat));
+  if (pl->f64)
+    OFDM_TRY(task4_run<double>(pl, drx, n_frames, time_desync, freq_desync, mp_desync, dbits, dref, derr, (int64_t*)dtg, (double*)dfo,
+                               (int32_t*)difo, (int32_t*)dstat, dh, st));
+  else
+    OFDM_TRY(task4_run<float>(pl, drx, n_frames, time_desync, freq_desync, mp_desync, dbits, dref, derr, (int64_t*)dtg, (double*)dfo,
+                              (int32_t*)difo, (int32_t*)dstat, dh, st));
+  return st.finish();
+}
 
 int ofdm_AutoCorrFunction(const void* rx, int64_t len, int width_window, int nfft, void* rho_out,
                           int64_t* tg_position_out, double* freq_offset_out, int flags) {
@@ -379,13 +642,13 @@ int ofdm_fine_sync(const void* rx, int nfft, int64_t n_symb, const int32_t* pilo
   OFDM_TRY(st.fetch((tau_out || phase_out) ? est : nullptr, sizeof(est), &dest));
   const int64_t total = (int64_t)nfft * n_symb;
   if (f64) {
-    PilotView<double> pv{(const c64*)dx, (const c64*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb};
+    PilotView<double> pv{(const c64*)dx, (const c64*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0};
     hipLaunchKernelGGL(fine_tau_kernel<double>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, deltak, variant, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<double>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, time_desync, (double*)dest);
     hipLaunchKernelGGL(fine_apply_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, ctx().stream, (const c64*)dx,
                        (c64*)dout, nfft, n_symb, time_desync, freq_desync, (const double*)dest);
   } else {
-    PilotView<float> pv{(const c32*)dx, (const c32*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb};
+    PilotView<float> pv{(const c32*)dx, (const c32*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0};
     hipLaunchKernelGGL(fine_tau_kernel<float>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, deltak, variant, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<float>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, time_desync, (double*)dest);
     hipLaunchKernelGGL(fine_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, ctx().stream, (const c32*)dx,

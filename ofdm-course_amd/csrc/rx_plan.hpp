@@ -29,3 +29,20 @@ struct ofdm_rx_plan {
   size_t ws_gen_bytes = 0;
   void* d_dict = nullptr;  // constellation table in the plan's precision (ofdm_tx_frames)
 };
+
+// view of a plan for the fast / split stages
+inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {
+  pv.nfft = pl->nfft; pv.t_guard = pl->t_guard; pv.n_symb = pl->n_symb; pv.n_carrier = pl->n_carrier;
+  pv.np = pl->np; pv.nd = pl->nd; pv.k_atoms = pl->k_atoms; pv.taps = pl->taps; pv.bps = pl->bps;
+  pv.f64 = pl->f64; pv.frame_words = pl->frame_words;
+  pv.d_prole = pl->d_prole; pv.d_drole = pl->d_drole; pv.d_pilots = pl->d_pilots; pv.d_sct = pl->d_sct;
+  pv.d_gram = pl->d_gram; pv.dict = &pl->dict; pv.cinfo = &pl->cinfo;
+  pv.ws_stash = &pl->ws_stash; pv.ws_ypil = &pl->ws_ypil; pv.ws_tapidx = &pl->ws_tapidx; pv.ws_tapx = &pl->ws_tapx;
+  pv.ws_frames = &pl->ws_frames;
+  pv.ev = pl->timing ? pl->ev : nullptr;
+  pv.comb_lg_up = pl->comb_lg_up;
+  pv.comb_m = pl->comb_m;
+  pv.fused_out = &pl->last_fused;
+  pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
+  pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
+}

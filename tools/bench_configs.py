@@ -96,8 +96,27 @@ def c3():
     res = {"config": "C3", "Nfft": Nfft, "symbols_per_frame": N_symb, "dtype": "f32",
            "ms_per_frame": ms, "sym_per_s": N_symb / ms * 1e3, "TgPosition": int(pos), "IFO": float(ifo),
            "BER": float(ofdm.BER_func(torch.from_numpy(bits).to(dev), out)),
-           "note": "one 50-symbol frame per call sequence (11 launches + 3 host scalars): launch-latency bound, "
-                   "a batched sync chain is a next-round row"}
+           "note": "per_call = one 50-symbol frame per call sequence (11 launches + 3 host scalars), launch-latency bound; "
+                   "batched = ofdm_rx_chain_task4 over 1024 frames with their own STO / CFO draws"}
+    # batched form: the same receiver over many frames in one call (ofdm_rx_chain_task4), each frame its own STO / CFO
+    F = 1024
+    rng = np.random.default_rng(3)
+    plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, pv[:, 0], int(np.ceil(N_carrier / 6)), 3, const,
+                       precision="fp32", device=0)
+    gen = plan.tx_frames(F, h=None, SNR=None, seed=9, device=dev)                       # clean TX frames, then per-frame impairments
+    rxb = torch.empty_like(gen["rx"].t().contiguous())
+    for f in range(F):
+        yf = gen["rx"][:, f].contiguous()
+        yf, _ = ofdm.Noise(30.0, yf, seed=9, stream=f)
+        yf = ofdm.add_CFO(ofdm.add_STO(yf, int(rng.integers(0, Nfft + Tg + 1))), float(rng.integers(0, 31)) + rng.random() - 0.5, Nfft)
+        rxb[f] = ofdm.apply_channel(yf, h)
+    rxb = rxb.t()
+    msb, outb = timed(lambda: ofdm.rx_chain_task4(plan, rxb, 1, 1, 1, ref_bits_packed=gen["packed"]), reps=5, warm=2)
+    okf = (outb["status"] >= 0)
+    res["batched"] = {"frames": F, "ms": msb, "sym_per_s": F * N_symb / msb * 1e3,
+                      "hbm_frac": (Nfft + Tg) * 8 * 3 * F * N_symb / (msb * 1e-3) / 1e9 / HBM,
+                      "frames_with_ifo_line": int(okf.sum().item()),
+                      "median_frame_BER": float(torch.median(outb["errors"].float() / plan.frame_bits).item())}
     # the O(L) autocorrelation alone on a long stream (HBM-bound kernel)
     long_rx = rx.repeat(200)
     ms2, _ = timed(lambda: ofdm.AutoCorrFunction(long_rx, Tg, Nfft), reps=5)
