@@ -21,9 +21,10 @@ static unsigned ew_grid(int64_t total, int per_block = 256) {
 // ---------------------------------------------------------------------------------------------
 // AutoCorrFunction.m:3-7.  rho(n) = sum_W x[m] conj(x[m+N]) / sqrt(sum_W |x[m]|^2 * sum_W |x[m+N]|^2)
 // for every n.  The reference is O(L*W); here each workgroup owns a tile of ACF_TILE outputs, forms
-// the three running sums as tile-local exclusive prefix sums (rows of 256 elements, wave-shuffle
-// scan + carry, double accumulation) in LDS and takes S[n+W]-S[n]: O(L) work, each sample read
-// twice (once as x[m], once as x[m+N]) and rho written once.
+// the three running sums as tile-local exclusive prefix sums in LDS (double accumulation: every thread
+// scans its own run of <= 8 consecutive products serially, ONE wave-shuffle scan of the 256 run totals
+// ties them together) and takes S[n+W]-S[n]: O(L) work, each sample read twice (once as x[m], once as
+// x[m+N]) and rho written once.
 // ---------------------------------------------------------------------------------------------
 constexpr int ACF_TILE = 1024;
 constexpr int ACF_THREADS = 256;
@@ -44,40 +45,43 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   rho += (int64_t)blockIdx.y * n_out;
   __shared__ acf4 S[ACF_ELEMS + 1];                  // exclusive prefix: S[i] = sum_{m<i}
   __shared__ acf4 wtot[ACF_THREADS / 64];
-  __shared__ acf4 carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * ACF_TILE;
   const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
   const int m_cnt = n_here + W - 1;                  // elements needed: m = n0 .. n0+n_here+W-2
-  if (tid == 0) { carry_s = acf4{0, 0, 0, 0}; S[0] = acf4{0, 0, 0, 0}; }
-  __syncthreads();
-  for (int base = 0; base < m_cnt; base += ACF_THREADS) {
-    const int i = base + tid;
-    acf4 v{0, 0, 0, 0};
-    if (i < m_cnt) {
-      const int64_t m = n0 + i;                      // m + nfft < len is guaranteed by n_out
-      const cx<T> a = x[m], b = x[m + nfft];
-      const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
-      v.pr = ar * br + ai * bi;                      // a * conj(b)
-      v.pi = ai * br - ar * bi;
-      v.e1 = ar * ar + ai * ai;
-      v.e2 = br * br + bi * bi;
-    }
-    // inclusive scan inside the wave
-    for (int d = 1; d < 64; d <<= 1) {
-      acf4 u = acf_shfl_up(v, d);
-      if (lane >= d) v = acf_add(v, u);
-    }
-    if (lane == 63) wtot[wid] = v;
-    __syncthreads();
-    acf4 off = carry_s;
-    for (int w = 0; w < wid; ++w) off = acf_add(off, wtot[w]);
-    v = acf_add(v, off);
-    if (i < m_cnt) S[i + 1] = v;
-    __syncthreads();
-    if (tid == ACF_THREADS - 1) carry_s = v;         // running total after this row
-    __syncthreads();
+  // (1) products, coalesced: S[i+1] <- element i
+  if (tid == 0) S[0] = acf4{0, 0, 0, 0};
+  for (int i = tid; i < m_cnt; i += ACF_THREADS) {
+    const int64_t m = n0 + i;                        // m + nfft < len is guaranteed by n_out
+    const cx<T> a = x[m], b = x[m + nfft];
+    const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+    S[i + 1] = acf4{ar * br + ai * bi,               // a * conj(b)
+                    ai * br - ar * bi, ar * ar + ai * ai, br * br + bi * bi};
   }
+  __syncthreads();
+  // (2) every thread makes the inclusive prefix of its own run of E consecutive elements in registers / LDS ...
+  const int E = (m_cnt + ACF_THREADS - 1) / ACF_THREADS;          // <= 8 (ACF_ELEMS / ACF_THREADS)
+  const int lo_i = tid * E, hi_i = (lo_i + E < m_cnt) ? lo_i + E : m_cnt;
+  acf4 run{0, 0, 0, 0};
+  for (int i = lo_i; i < hi_i; ++i) {
+    run = acf_add(run, S[i + 1]);
+    S[i + 1] = run;
+  }
+  // (3) ... one exclusive scan of the 256 run totals (wave shuffle scan + carry of the earlier wavefronts) ...
+  acf4 v = run;
+  for (int d = 1; d < 64; d <<= 1) {
+    acf4 u = acf_shfl_up(v, d);
+    if (lane >= d) v = acf_add(v, u);
+  }
+  if (lane == 63) wtot[wid] = v;
+  __syncthreads();
+  acf4 off{0, 0, 0, 0};
+  for (int w = 0; w < wid; ++w) off = acf_add(off, wtot[w]);
+  // exclusive offset of this thread = (inclusive wave scan - own total) + earlier wavefronts
+  off = acf_add(off, acf4{v.pr - run.pr, v.pi - run.pi, v.e1 - run.e1, v.e2 - run.e2});
+  // (4) ... added to the thread's entries: S[i+1] = sum_{m <= i}
+  for (int i = lo_i; i < hi_i; ++i) S[i + 1] = acf_add(S[i + 1], off);
+  __syncthreads();
   for (int i = tid; i < n_here; i += ACF_THREADS) {
     const acf4 hi = S[i + W], lo = S[i];
     const double pr = hi.pr - lo.pr, pi = hi.pi - lo.pi, e1 = hi.e1 - lo.e1, e2 = hi.e2 - lo.e2;
