@@ -428,21 +428,34 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   const bool f64 = std::is_same<T, double>::value;
   hipStream_t s = ctx().stream;
   const bool sync = time_desync || freq_desync;
-  void *drho = nullptr, *dres, *dresv, *dy, *dseg, *dspec, *dfirst, *dX, *dest, *dhp, *dH;
-  OFDM_TRY(st.scratch(sizeof(int64_t) * 2 * F, &dres));
-  OFDM_TRY(st.scratch(sizeof(double) * 2 * F, &dresv));
-  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)len * F, &dy));
-  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * S * F, &dX));
-  OFDM_TRY(st.scratch(sizeof(double) * 2 * F, &dest));
-  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)np * F, &dhp));
-  OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)nc * F, &dH));
+  // intermediates live in one plan-owned arena (grown on demand): no allocation on the steady-state path
+  void *drho = nullptr, *dres, *dresv, *dy, *dseg = nullptr, *dspec = nullptr, *dfirst = nullptr, *dX, *dest, *dhp, *dH;
+  size_t need = 0;
+  auto reserve = [&](size_t bytes) { const size_t o = need; need += (bytes + 255) & ~size_t(255); return o; };
+  const size_t o_res = reserve(sizeof(int64_t) * 2 * F), o_resv = reserve(sizeof(double) * 2 * F);
+  const size_t o_y = reserve(sizeof(cx<T>) * (size_t)len * F), o_X = reserve(sizeof(cx<T>) * (size_t)N * S * F);
+  const size_t o_est = reserve(sizeof(double) * 2 * F), o_hp = reserve(sizeof(cx<T>) * (size_t)np * F);
+  const size_t o_H = reserve(sizeof(cx<T>) * (size_t)nc * F);
+  const size_t o_rho = reserve(sync && n_out > 0 ? sizeof(cx<T>) * (size_t)n_out * F : 0);
+  const size_t o_seg = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
+  const size_t o_spec = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
+  const size_t o_first = reserve(freq_desync ? sizeof(int64_t) * F : 0);
+  if (pl->ws_t4_bytes < need) {
+    OFDM_HIP(hipStreamSynchronize(s));
+    if (pl->ws_t4) { (void)hipFree(pl->ws_t4); pl->ws_t4 = nullptr; pl->ws_t4_bytes = 0; }
+    OFDM_HIP(hipMalloc(&pl->ws_t4, need));
+    pl->ws_t4_bytes = need;
+  }
+  unsigned char* arena = (unsigned char*)pl->ws_t4;
+  dres = arena + o_res; dresv = arena + o_resv; dy = arena + o_y; dX = arena + o_X; dest = arena + o_est;
+  dhp = arena + o_hp; dH = arena + o_H;
   OFDM_HIP(hipMemsetAsync(dstat, 0, sizeof(int32_t) * F, s));
   OFDM_HIP(hipMemsetAsync(dtg, 0, sizeof(int64_t) * F, s));
   OFDM_HIP(hipMemsetAsync(dfo, 0, sizeof(double) * F, s));
   OFDM_HIP(hipMemsetAsync(difo, 0, sizeof(int32_t) * F, s));
   if (sync) {
     OFDM_ARG(n_out > 0 && Tg >= 1 && Tg <= ACF_MAXW, "rx_chain_task4: frame shorter than T_guard + Nfft, or T_guard outside 1..%d", ACF_MAXW);
-    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)n_out * F, &drho));
+    drho = arena + o_rho;
     hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
                        N, (cx<T>*)drho, n_out);
     hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
@@ -457,9 +470,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   OFDM_TRY(check_launch("t4_align_kernel"));
   if (freq_desync) {
     OFDM_ARG(len >= 2 * (int64_t)N, "rx_chain_task4: rx_signal(Nfft+1:2*Nfft) exceeds the frame");
-    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * F, &dseg));
-    OFDM_TRY(st.scratch(sizeof(cx<T>) * (size_t)N * F, &dspec));
-    OFDM_TRY(st.scratch(sizeof(int64_t) * F, &dfirst));
+    dseg = arena + o_seg; dspec = arena + o_spec; dfirst = arena + o_first;
     hipLaunchKernelGGL(t4_segment_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)dy, (cx<T>*)dseg, len, N);
     OFDM_TRY(demod_device(dseg, dspec, N, F, 0, f64));
     hipLaunchKernelGGL(first_above_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)dspec, (int64_t)N, 0.77,
