@@ -4,9 +4,13 @@
 
 namespace ofdm {
 
+bool modem_wave_supported(int nfft);                                                              // ofdm_modem_wave.hip
+int modem_wave_run(const void* in, void* out, int nfft, int64_t n_symb, int t_guard, bool f64, bool modulate);
+
 // ---------------------------------------------------------------------------------------------
 // OFDM_demodulator -- T5/OFDM_demodulator.m:2-10: drop rows 1..Tg, fft per column (unscaled).
-// One transform per N/8 threads; the CP rows are never read.
+// Generic form (Nfft 64..256 and 8192; 512..4096 run on the wave-local transform, ofdm_modem_wave.hip):
+// one transform per N/8 threads; the CP rows are never read.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int N>
 __global__ __launch_bounds__(fft_wg_threads(N)) void demod_kernel(const cx<T>* __restrict__ y,
@@ -160,6 +164,7 @@ static int launch_mod(const void* x, void* y, const void* tw, int64_t n_symb, in
 // internal device-pointer entry points reused by other translation units
 int demod_device(const void* y, void* x, int nfft, int64_t n_symb, int t_guard, bool f64) {
   if (n_symb == 0) return OFDM_OK;
+  if (modem_wave_supported(nfft)) return modem_wave_run(y, x, nfft, n_symb, t_guard, f64, false);
   const void* tw = nullptr;
   OFDM_TRY(get_twiddles(nfft, f64, &tw));
 #define CALL(NN)                                                                  \
@@ -193,6 +198,7 @@ int demod_keep_device(const void* y, void* x, int nfft, int64_t n_symb, int t_gu
 
 int mod_device(const void* x, void* y, int nfft, int64_t n_symb, int t_guard, bool f64) {
   if (n_symb == 0) return OFDM_OK;
+  if (modem_wave_supported(nfft)) return modem_wave_run(x, y, nfft, n_symb, t_guard, f64, true);
   const void* tw = nullptr;
   OFDM_TRY(get_twiddles(nfft, f64, &tw));
 #define CALL(NN)                                                                \
