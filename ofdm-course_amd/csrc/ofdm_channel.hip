@@ -1,5 +1,7 @@
 // Channel side: get_MP_channel_resp + the inline conv of the drivers, Noise (counter-based AWGN),
 // add_STO, add_CFO.
+#include <type_traits>
+
 #include "ofdm_common.hpp"
 
 namespace ofdm {
@@ -107,15 +109,23 @@ __global__ void awgn_kernel(const cx<T>* __restrict__ xall, cx<T>* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t r[4];
     philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), stream, 0u, k0, k1, r);
-    // Box-Muller in double for both precisions (the draw is an INPUT of the chain; keeps the
-    // fp32 and fp64 modes on the same noise realisation up to the final rounding)
+    // Box-Muller on the same Philox words in both precisions (the draw is an INPUT of the chain): double arithmetic in
+    // parity mode; in fp32 mode the uniform words are still formed in double, log / sincospi / sqrt run in float --
+    // the same realisation to ~1e-7 of a noise sample, at twice the rate (the double form made Noise compute-bound)
     const double u0 = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
     const double u1 = ((double)r[1] + 0.5) * 2.3283064365386963e-10;
-    const double rad = sqrt(-2.0 * log(u0));
-    double sn, cs;
-    sincospi(2.0 * u1, &sn, &cs);
     const cx<T> v = x[i];
-    y[i] = mk<T>((T)((double)v.x + sg * rad * cs), (T)((double)v.y + sg * rad * sn));
+    if constexpr (std::is_same<T, float>::value) {
+      const float rad = sqrtf(-2.0f * logf((float)u0)) * (float)sg;
+      float sn, cs;
+      sincospif((float)(2.0 * u1), &sn, &cs);
+      y[i] = mk<T>(v.x + rad * cs, v.y + rad * sn);
+    } else {
+      const double rad = sqrt(-2.0 * log(u0));
+      double sn, cs;
+      sincospi(2.0 * u1, &sn, &cs);
+      y[i] = mk<T>((T)((double)v.x + sg * rad * cs), (T)((double)v.y + sg * rad * sn));
+    }
   }
 }
 
