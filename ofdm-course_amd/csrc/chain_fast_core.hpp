@@ -413,7 +413,8 @@ int omp_batch_run(const FastParams<T>& P, int64_t n_frames);                    
 
 template <typename T>
 int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk, int x_stride, bool hext, int64_t n_frames,
-                 void* bits, const void* ref, void* errs, void* h_out, void* idx_out);                 // ofdm_chain_split.hip
+                 void* bits, const void* ref, void* errs, void* h_out, void* idx_out, const double* fine_est, int time_desync,
+                 int freq_desync);                                                                     // ofdm_chain_split.hip
 
 // ofdm_chain_mmse.hip: the MMSE estimator of a plan as one operator W^T [np][m_pad] and its batched application
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,

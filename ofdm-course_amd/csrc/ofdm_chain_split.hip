@@ -36,9 +36,15 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
                                                        int x_stride /* rows per symbol column of xk */, int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                        const uint32_t* __restrict__ ref_bits,
                                                        uint32_t* __restrict__ errors_out, cx<T>* __restrict__ h_out,
-                                                       int32_t* __restrict__ index_out, DemapTable<T> tab) {
+                                                       int32_t* __restrict__ index_out, DemapTable<T> tab,
+                                                       const double* __restrict__ fine_est /* [n_frames][2] or null */,
+                                                       int time_desync, int freq_desync) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cx<T>* geq = (cx<T>*)smem;                                            // [n_carrier]
+  // fine_est: the residual timing / phase estimates of fine_sync (tau, phase) per frame; its rotation
+  // exp(j (2 pi tau k + phase)) (fine_sync.m:36-43) is applied to every sample as it is read, with the rounding of the
+  // separate pass, instead of rewriting X
+  c64* rot = (c64*)smem;                                                // [n_carrier] when fine_est, else empty
+  cx<T>* geq = (cx<T>*)(rot + (fine_est ? P.n_carrier : 0));            // [n_carrier]
   uint8_t* codes = (uint8_t*)(geq + P.n_carrier);                       // [n_symb * nd] (+ padding to 32)
   __shared__ unsigned int sh_err;
   __shared__ int sh_tidx[FAST_MAXT];
@@ -101,6 +107,19 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
         }
       }
     }
+    if (fine_est) {
+      const double tau = fine_est[2 * f], ph = fine_est[2 * f + 1];
+      double psn = 0.0, pcs = 1.0;
+      if (freq_desync) sincos(ph, &psn, &pcs);
+      for (int k = gid; k < nc; k += 256) {
+        double cs = 1.0, sn = 0.0;
+        if (time_desync) {
+          const double t = tau * (double)k;
+          sincospi(2.0 * (t - floor(t)), &sn, &cs);
+        }
+        rot[k] = c64{cs * pcs - sn * psn, sn * pcs + cs * psn};
+      }
+    }
     __syncthreads();
     const cx<T>* xf = xk + f * P.n_symb * (int64_t)x_stride;
     // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by
@@ -123,8 +142,14 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
         for (int v = 0; v < 2; ++v)
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (dv[u] >= 0 && s0 + v < P.n_symb)
-              codes[(s0 + v) * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xv[v][u] * geq[k0 + 256 * u]);
+            if (dv[u] >= 0 && s0 + v < P.n_symb) {
+              cx<T> xs = xv[v][u];
+              if (fine_est) {
+                const c64 r = rot[k0 + 256 * u];
+                xs = mk<T>((T)((double)xs.x * r.x - (double)xs.y * r.y), (T)((double)xs.x * r.y + (double)xs.y * r.x));
+              }
+              codes[(s0 + v) * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xs * geq[k0 + 256 * u]);
+            }
       }
     __syncthreads();
     unsigned int err = 0;
@@ -260,18 +285,21 @@ bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t n
 // equalise + demap + pack + BER of n_frames frames from X columns of x_stride rows (rows 1..N_carrier are read)
 template <typename T>
 int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk, int x_stride, bool hext, int64_t n_frames,
-                 void* bits, const void* ref, void* errs, void* h_out, void* idx_out) {
+                 void* bits, const void* ref, void* errs, void* h_out, void* idx_out, const double* fine_est, int time_desync,
+                 int freq_desync) {
   hipStream_t st = ctx().stream;
   DemapTable<T> tab;
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
-  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31)) +
+                     (fine_est ? sizeof(c64) * (size_t)pv.n_carrier : 0);
   OFDM_ARG(dyn <= 150 * 1024, "rx_chain: equalise / demap stage needs %zu bytes of LDS", dyn);
   auto launch = [&](auto kern) -> int {
     int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
     if (const char* e = getenv("OFDM_EQD_WG_PER_CU")) per_cu = std::max(1, atoi(e));
     const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), dyn, st, P, pv.nfft, xk, x_stride, n_frames, (uint32_t*)bits,
-                       (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab);
+                       (const uint32_t*)ref, (uint32_t*)errs, (cx<T>*)h_out, (int32_t*)idx_out, tab, fine_est, time_desync,
+                       freq_desync);
     return OFDM_OK;
   };
   const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
@@ -287,9 +315,9 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
   return check_launch("eq_demap_kernel");
 }
 template int eq_demap_run<float>(const FastPlanView&, const FastParams<float>&, const cx<float>*, int, bool, int64_t, void*,
-                                 const void*, void*, void*, void*);
+                                 const void*, void*, void*, void*, const double*, int, int);
 template int eq_demap_run<double>(const FastPlanView&, const FastParams<double>&, const cx<double>*, int, bool, int64_t, void*,
-                                  const void*, void*, void*, void*);
+                                  const void*, void*, void*, void*, const double*, int, int);
 
 template <typename T>
 static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int64_t n_frames, void* bits,
@@ -319,7 +347,7 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   if (mmse) OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
   else OFDM_TRY(omp_batch_run<T>(P, n_frames));
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
-  OFDM_TRY(eq_demap_run<T>(pv, P, xk, pv.n_carrier, mmse, n_frames, bits, ref, errs, h_out, idx_out));
+  OFDM_TRY(eq_demap_run<T>(pv, P, xk, pv.n_carrier, mmse, n_frames, bits, ref, errs, h_out, idx_out, nullptr, 0, 0));
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
   return OFDM_OK;
 }

@@ -380,17 +380,160 @@ __global__ void t4_ifo_kernel(cx<T>* __restrict__ y, int64_t len, int nfft, cons
   }
 }
 
+// ---- the same three stages without the intermediate streams (Nfft 512..4096): sample i of the aligned, CFO- and
+// IFO-corrected stream of a frame, computed from rx on the fly with the roundings of the separate stages
+// (round to T after the add_CFO(-FreqOffset) rotation and again after the add_CFO(-IFO) rotation).
+template <typename T>
+__device__ __forceinline__ cx<T> t4_raw(const cx<T>* __restrict__ x, int64_t i, int64_t len, int sym_len, int time_desync,
+                                        int64_t pos) {
+  if (!time_desync) return x[i];
+  const int64_t i1 = i - sym_len;
+  return (i1 >= 0 && i1 < len - pos && i1 + pos < len) ? x[i1 + pos] : mk<T>(0, 0);
+}
+template <typename T>
+__device__ __forceinline__ cx<T> t4_rotate(cx<T> v, double cfo, int64_t i, double inv_nfft) {
+  const double t = cfo * (double)i * inv_nfft;
+  double sn, cs;
+  sincospi(2.0 * (t - floor(t)), &sn, &cs);
+  return mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
+}
+
+// rx_signal(Nfft+1 : 2*Nfft) after the STO fix and add_CFO(-FreqOffset), straight from rx (remove_IFO.m:5)
+template <typename T>
+__global__ void t4_segment_direct_kernel(const cx<T>* __restrict__ rx, cx<T>* __restrict__ seg, int64_t len, int sym_len, int nfft,
+                                         int time_desync, const int64_t* __restrict__ tg, const double* __restrict__ fo) {
+  const int64_t f = blockIdx.y;
+  const int64_t pos = time_desync ? tg[f] : 0;
+  const double cfo = -fo[f], inv = 1.0 / (double)nfft;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nfft; k += gridDim.x * blockDim.x) {
+    const int64_t i = (int64_t)nfft + k;
+    seg[f * nfft + k] = t4_rotate<T>(t4_raw<T>(rx + f * len, i, len, sym_len, time_desync, pos), cfo, i, inv);
+  }
+}
+
+__global__ void t4_ifo_finalize_kernel(const int64_t* __restrict__ first, int32_t* __restrict__ ifo_out,
+                                       int32_t* __restrict__ status, int64_t n_frames) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  ifo_out[f] = (int32_t)first[f];
+  if (first[f] < 0 && status[f] >= 0) status[f] = -1;
+}
+
+// OFDM_demodulator of every symbol of every frame on the wave-local transform, its samples taken from rx through
+// t4_raw / t4_rotate: no aligned / corrected copy of the batch is ever written.
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restrict__ rx, cx<T>* __restrict__ X,
+                                                           const cx<T>* __restrict__ tw, int64_t len, int t_guard, int n_symb,
+                                                           int64_t n_frames, int time_desync, int freq_desync,
+                                                           const int64_t* __restrict__ tg, const double* __restrict__ fo,
+                                                           const int32_t* __restrict__ ifo) {
+  constexpr int N = 512 * NW;
+  constexpr int BPT = NW > 1 ? 8 / NW : 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* lwv = (cx<T>*)smem;
+  cx<T>* const ex = lwv;
+  cx<T>* twl = lwv + NW * WAVE_LDS_ELEMS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
+  DifTw<T, NW> dt;
+  wave_tw_fill<T, NW>(twl, tw);
+  dif_tw_init<T, NW>(dt, gid, tw);
+  cx<T> twb[7];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) twb[t - 1] = tw[(t * (lane & 7) * 8) * NW];
+  __syncthreads();
+  const int sym_len = N + t_guard;
+  const double inv = 1.0 / (double)N;
+  const int64_t total = n_frames * n_symb;
+  // slot e of this thread <-> sample m_e of the symbol (the layout frame_load uses)
+  auto slot_m = [&](int e) -> int {
+    if constexpr (NW == 1) return lane + 64 * e;
+    else return gid * BPT + (e / NW) + 512 * (e % NW);
+  };
+  auto load_raw = [&](cx<T> (&dst)[8], int64_t sg) {
+    const int64_t f = sg / n_symb;
+    const int sy = (int)(sg - f * n_symb);
+    const int64_t pos = time_desync ? tg[f] : 0;
+    const cx<T>* xf = rx + f * len;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = t4_raw<T>(xf, (int64_t)sy * sym_len + t_guard + slot_m(e), len, sym_len, time_desync, pos);
+  };
+  cx<T> v[8], nx[8];
+  if ((int64_t)blockIdx.x < total) load_raw(nx, blockIdx.x);
+  for (int64_t sg = blockIdx.x; sg < total; sg += gridDim.x) {
+    const int64_t f = sg / n_symb;
+    const int sy = (int)(sg - f * n_symb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = nx[e];
+    if (sg + gridDim.x < total) load_raw(nx, sg + gridDim.x);
+    if (freq_desync) {
+      const double c1 = -fo[f];
+      const int32_t fi = ifo[f];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t i = (int64_t)sy * sym_len + t_guard + slot_m(e);
+        v[e] = t4_rotate<T>(v[e], c1, i, inv);
+        if (fi > 0) v[e] = t4_rotate<T>(v[e], -(double)fi, i, inv);
+      }
+    }
+    if constexpr (NW > 1) {
+      dif_stage<T, NW>(v, dt);
+      __syncthreads();
+      dif_scatter<T, NW>(v, gid, ex);
+      __syncthreads();
+      dif_gather<T>(v, wave, lane, ex);
+    } else {
+      __syncthreads();
+    }
+    wave_fft512<T, false>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lwv[NW * (lane + 64 * t) + wave] = v[t];
+    __syncthreads();
+    cx<T>* dst = X + sg * (int64_t)N;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[gid + 64 * NW * e] = lwv[gid + 64 * NW * e];
+  }
+}
+
+template <typename T, int NW>
+static int t4_demod_launch(const void* rx, void* X, const void* tw, int64_t len, int t_guard, int n_symb, int64_t F, int td, int fd,
+                           const int64_t* tg, const double* fo, const int32_t* ifo) {
+  const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS);
+  auto kern = t4_demod_kernel<T, NW>;
+  const int per_cu = resident_blocks_per_cu((const void*)kern, 64 * NW, dyn);
+  const unsigned grid = (unsigned)std::min<int64_t>(F * n_symb, (int64_t)ctx().num_cu * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), dyn, ctx().stream, (const cx<T>*)rx, (cx<T>*)X, (const cx<T>*)tw, len, t_guard,
+                     n_symb, F, td, fd, tg, fo, ifo);
+  return check_launch("t4_demod_kernel");
+}
+
 // estimate_channel.m:6 per frame, then the spline operator of :8 restricted to rows 1..N_carrier (what equalize_signal reads)
 template <typename T>
 __global__ void t4_mean_pilots_kernel(const cx<T>* __restrict__ X, const cx<T>* __restrict__ tx, const int32_t* __restrict__ pc0,
-                                      cx<T>* __restrict__ hp, int nfft, int np, int n_symb) {
+                                      cx<T>* __restrict__ hp, int nfft, int np, int n_symb,
+                                      const double* __restrict__ fine_est /* rotation not yet applied to X, or null */,
+                                      int time_desync, int freq_desync) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t f = blockIdx.y;
   if (p >= np) return;
   const cx<T>* rx = X + f * (int64_t)nfft * n_symb;
+  double rc = 1.0, rs = 0.0;
+  if (fine_est) {                                                  // the rotation of fine_apply_kernel for row pc0[p]
+    const double tau = fine_est[2 * f], ph = fine_est[2 * f + 1];
+    double psn = 0.0, pcs = 1.0, cs = 1.0, sn = 0.0;
+    if (freq_desync) sincos(ph, &psn, &pcs);
+    if (time_desync) {
+      const double t = tau * (double)pc0[p];
+      sincospi(2.0 * (t - floor(t)), &sn, &cs);
+    }
+    rc = cs * pcs - sn * psn;
+    rs = sn * pcs + cs * psn;
+  }
   double ar = 0, ai = 0;
   for (int s = 0; s < n_symb; ++s) {
-    const cx<T> q = cdiv(rx[(int64_t)s * nfft + pc0[p]], tx[s * np + p]);
+    cx<T> xv = rx[(int64_t)s * nfft + pc0[p]];
+    if (fine_est) xv = mk<T>((T)((double)xv.x * rc - (double)xv.y * rs), (T)((double)xv.x * rs + (double)xv.y * rc));
+    const cx<T> q = cdiv(xv, tx[s * np + p]);
     ar += (double)q.x;
     ai += (double)q.y;
   }
@@ -465,46 +608,78 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     OFDM_TRY(check_launch("AutoCorrFunction stage"));
   }
   const unsigned gl = (unsigned)std::min<int64_t>((len + 255) / 256, 64);
-  hipLaunchKernelGGL(t4_align_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dy, len, N + Tg, N,
-                     sync ? time_desync : 0, sync ? freq_desync : 0, (const int64_t*)dtg, (const double*)dfo);
-  OFDM_TRY(check_launch("t4_align_kernel"));
-  if (freq_desync) {
-    OFDM_ARG(len >= 2 * (int64_t)N, "rx_chain_task4: rx_signal(Nfft+1:2*Nfft) exceeds the frame");
-    dseg = arena + o_seg; dspec = arena + o_spec; dfirst = arena + o_first;
-    hipLaunchKernelGGL(t4_segment_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)dy, (cx<T>*)dseg, len, N);
-    OFDM_TRY(demod_device(dseg, dspec, N, F, 0, f64));
-    hipLaunchKernelGGL(first_above_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)dspec, (int64_t)N, 0.77,
-                       (int64_t*)dfirst);
-    hipLaunchKernelGGL(t4_ifo_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (cx<T>*)dy, len, N, (const int64_t*)dfirst, difo, dstat);
-    OFDM_TRY(check_launch("remove_IFO stage"));
+  const int td_eff = sync ? time_desync : 0, fd_eff = sync ? freq_desync : 0;
+  const bool direct = (N == 512 || N == 1024 || N == 2048 || N == 4096) && !getenv("OFDM_T4_STAGED");
+  if (freq_desync) OFDM_ARG(len >= 2 * (int64_t)N, "rx_chain_task4: rx_signal(Nfft+1:2*Nfft) exceeds the frame");
+  if (direct) {
+    // no aligned / corrected copy of the batch: the IFO search reads its segment, the demodulator its samples, from rx
+    if (freq_desync) {
+      dseg = arena + o_seg; dspec = arena + o_spec; dfirst = arena + o_first;
+      hipLaunchKernelGGL(t4_segment_direct_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dseg,
+                         len, N + Tg, N, td_eff, (const int64_t*)dtg, (const double*)dfo);
+      OFDM_TRY(demod_device(dseg, dspec, N, F, 0, f64));
+      hipLaunchKernelGGL(first_above_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)dspec, (int64_t)N, 0.77,
+                         (int64_t*)dfirst);
+      hipLaunchKernelGGL(t4_ifo_finalize_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dfirst, difo, dstat, F);
+      OFDM_TRY(check_launch("remove_IFO stage"));
+    }
+    const void* twd = nullptr;
+    OFDM_TRY(get_twiddles(N, f64, &twd));
+    switch (N / 512) {
+      case 1: OFDM_TRY((t4_demod_launch<T, 1>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
+      case 2: OFDM_TRY((t4_demod_launch<T, 2>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
+      case 4: OFDM_TRY((t4_demod_launch<T, 4>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
+      default: OFDM_TRY((t4_demod_launch<T, 8>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
+    }
+  } else {
+    hipLaunchKernelGGL(t4_align_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dy, len, N + Tg, N,
+                       td_eff, fd_eff, (const int64_t*)dtg, (const double*)dfo);
+    OFDM_TRY(check_launch("t4_align_kernel"));
+    if (freq_desync) {
+      dseg = arena + o_seg; dspec = arena + o_spec; dfirst = arena + o_first;
+      hipLaunchKernelGGL(t4_segment_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)dy, (cx<T>*)dseg, len, N);
+      OFDM_TRY(demod_device(dseg, dspec, N, F, 0, f64));
+      hipLaunchKernelGGL(first_above_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)dspec, (int64_t)N, 0.77,
+                         (int64_t*)dfirst);
+      hipLaunchKernelGGL(t4_ifo_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (cx<T>*)dy, len, N, (const int64_t*)dfirst, difo, dstat);
+      OFDM_TRY(check_launch("remove_IFO stage"));
+    }
+    OFDM_TRY(demod_device(dy, dX, N, (int64_t)S * F, Tg, f64));                       // T4:308-310
   }
-  OFDM_TRY(demod_device(dy, dX, N, (int64_t)S * F, Tg, f64));                       // T4:308-310
-  // pilot matrix [np x S] = the plan's pilot column on every symbol (T4:28-31)
-  std::vector<cx<T>> col(np), txm((size_t)np * S);
-  OFDM_HIP(hipMemcpyAsync(col.data(), pl->d_pilots, sizeof(cx<T>) * np, hipMemcpyDeviceToHost, s));
-  OFDM_HIP(hipStreamSynchronize(s));
-  for (int sy = 0; sy < S; ++sy) std::copy(col.begin(), col.end(), txm.begin() + (size_t)sy * np);
-  const void *dtx, *dW;
-  OFDM_TRY(st.upload(txm.data(), sizeof(cx<T>) * txm.size(), &dtx));
+  // pilot matrix [np x S] = the plan's pilot column on every symbol (T4:28-31) and the spline operator of
+  // estimate_channel.m:8 for rows 1..N_carrier: built once per plan, kept on the device
+  if (!pl->d_t4_tx) {
+    std::vector<cx<T>> col(np), txm((size_t)np * S);
+    OFDM_HIP(hipMemcpyAsync(col.data(), pl->d_pilots, sizeof(cx<T>) * np, hipMemcpyDeviceToHost, s));
+    OFDM_HIP(hipStreamSynchronize(s));
+    for (int sy = 0; sy < S; ++sy) std::copy(col.begin(), col.end(), txm.begin() + (size_t)sy * np);
+    OFDM_HIP(hipMalloc(&pl->d_t4_tx, sizeof(cx<T>) * txm.size()));
+    OFDM_HIP(hipMemcpy(pl->d_t4_tx, txm.data(), sizeof(cx<T>) * txm.size(), hipMemcpyHostToDevice));
+    std::vector<double> xk(np), xq(nc), W;
+    for (int i = 0; i < np; ++i) xk[i] = pl->pilot_loc[i];
+    for (int i = 0; i < nc; ++i) xq[i] = i + 1.0;
+    OFDM_TRY(build_spline_operator(xk, xq, W));                                       // estimate_channel.m:8, rows 1..N_carrier
+    std::vector<T> Wt(W.begin(), W.end());
+    OFDM_HIP(hipMalloc(&pl->d_t4_w, sizeof(T) * Wt.size()));
+    OFDM_HIP(hipMemcpy(pl->d_t4_w, Wt.data(), sizeof(T) * Wt.size(), hipMemcpyHostToDevice));
+  }
+  const void *dtx = pl->d_t4_tx, *dW = pl->d_t4_w;
   if (sync) {
     OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
     const double deltak = (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0];       // fine_sync.m:6
     PilotView<T> pv{(const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, N, np, (int64_t)np * S, (int64_t)N * S};
     hipLaunchKernelGGL(fine_tau_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, deltak, 1 /* T4 variant */, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, time_desync, (double*)dest);
-    hipLaunchKernelGGL(fine_apply_kernel<T>, dim3(64, (unsigned)F), dim3(256), 0, s, (const cx<T>*)dX, (cx<T>*)dX, N, (int64_t)S,
-                       time_desync, freq_desync, (const double*)dest);
+    // staged form: rewrite X; otherwise the rotation is applied where X is read (pilot means, equaliser)
+    if (!direct)
+      hipLaunchKernelGGL(fine_apply_kernel<T>, dim3(64, (unsigned)F), dim3(256), 0, s, (const cx<T>*)dX, (cx<T>*)dX, N, (int64_t)S,
+                         time_desync, freq_desync, (const double*)dest);
     OFDM_TRY(check_launch("fine_sync stage"));
   }
+  const double* lazy_rot = (sync && direct) ? (const double*)dest : nullptr;
   if (mp_desync) {
-    std::vector<double> xk(np), xq(nc), W;
-    for (int i = 0; i < np; ++i) xk[i] = pl->pilot_loc[i];
-    for (int i = 0; i < nc; ++i) xq[i] = i + 1.0;
-    OFDM_TRY(build_spline_operator(xk, xq, W));                                       // estimate_channel.m:8, rows 1..N_carrier
-    std::vector<T> Wt(W.begin(), W.end());
-    OFDM_TRY(st.upload(Wt.data(), sizeof(T) * Wt.size(), &dW));
     hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s, (const cx<T>*)dX, (const cx<T>*)dtx,
-                       (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S);
+                       (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S, lazy_rot, time_desync, freq_desync);
     hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), (unsigned)F), dim3(128), 0, s, (const T*)dW, (const cx<T>*)dhp,
                        (cx<T>*)dH, nc, np);
   } else {
@@ -519,7 +694,8 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   OFDM_TRY(get_twiddles(N, f64, &tw));
   OFDM_TRY(fast_params_prepare<T>(pv2, tw, F, P));
   P.h_in = (const cx<T>*)dH;
-  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, N, true, F, dbits, dref, derr, dh_out, nullptr));   // T4:334-347
+  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, N, true, F, dbits, dref, derr, dh_out, nullptr, lazy_rot, time_desync,
+                           freq_desync));                                                                   // T4:334-347
   return OFDM_OK;
 }
 

@@ -28,6 +28,8 @@ struct ofdm_rx_plan {
   void* ws_gen = nullptr;  // ofdm_tx_frames: X / time-domain scratch for one chunk of frames
   size_t ws_gen_bytes = 0;
   void* d_dict = nullptr;  // constellation table in the plan's precision (ofdm_tx_frames)
+  void* d_t4_tx = nullptr; // ofdm_rx_chain_task4: pilot matrix [np x n_symb] and spline operator [n_carrier x np] (built once)
+  void* d_t4_w = nullptr;
   void* ws_t4 = nullptr;   // ofdm_rx_chain_task4: arena for its per-batch intermediates
   size_t ws_t4_bytes = 0;
 };
