@@ -49,38 +49,43 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   const int64_t n0 = (int64_t)blockIdx.x * ACF_TILE;
   const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
   const int m_cnt = n_here + W - 1;                  // elements needed: m = n0 .. n0+n_here+W-2
-  // (1) products, coalesced: S[i+1] <- element i
-  if (tid == 0) S[0] = acf4{0, 0, 0, 0};
-  for (int i = tid; i < m_cnt; i += ACF_THREADS) {
-    const int64_t m = n0 + i;                        // m + nfft < len is guaranteed by n_out
-    const cx<T> a = x[m], b = x[m + nfft];
-    const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
-    S[i + 1] = acf4{ar * br + ai * bi,               // a * conj(b)
-                    ai * br - ar * bi, ar * ar + ai * ai, br * br + bi * bi};
-  }
-  __syncthreads();
-  // (2) every thread makes the inclusive prefix of its own run of E consecutive elements in registers / LDS ...
-  const int E = (m_cnt + ACF_THREADS - 1) / ACF_THREADS;          // <= 8 (ACF_ELEMS / ACF_THREADS)
-  const int lo_i = tid * E, hi_i = (lo_i + E < m_cnt) ? lo_i + E : m_cnt;
+  // (1) every thread forms the products of its own run of E consecutive elements and their inclusive prefix in
+  //     registers (a wavefront still reads one contiguous span of x; the lines are reused across the run) ...
+  constexpr int EMAX = ACF_ELEMS / ACF_THREADS;                   // 8
+  const int E = (m_cnt + ACF_THREADS - 1) / ACF_THREADS;          // <= EMAX
+  const int lo_i = tid * E;
+  acf4 pre[EMAX];
   acf4 run{0, 0, 0, 0};
-  for (int i = lo_i; i < hi_i; ++i) {
-    run = acf_add(run, S[i + 1]);
-    S[i + 1] = run;
+#pragma unroll
+  for (int j = 0; j < EMAX; ++j) {
+    const int i = lo_i + j;
+    if (j < E && i < m_cnt) {
+      const int64_t m = n0 + i;                      // m + nfft < len is guaranteed by n_out
+      const cx<T> a = x[m], b = x[m + nfft];
+      const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+      run = acf_add(run, acf4{ar * br + ai * bi,     // a * conj(b)
+                              ai * br - ar * bi, ar * ar + ai * ai, br * br + bi * bi});
+    }
+    pre[j] = run;
   }
-  // (3) ... one exclusive scan of the 256 run totals (wave shuffle scan + carry of the earlier wavefronts) ...
+  // (2) ... one exclusive scan of the 256 run totals (wave shuffle scan + carry of the earlier wavefronts) ...
   acf4 v = run;
   for (int d = 1; d < 64; d <<= 1) {
     acf4 u = acf_shfl_up(v, d);
     if (lane >= d) v = acf_add(v, u);
   }
   if (lane == 63) wtot[wid] = v;
+  if (tid == 0) S[0] = acf4{0, 0, 0, 0};
   __syncthreads();
   acf4 off{0, 0, 0, 0};
   for (int w = 0; w < wid; ++w) off = acf_add(off, wtot[w]);
-  // exclusive offset of this thread = (inclusive wave scan - own total) + earlier wavefronts
   off = acf_add(off, acf4{v.pr - run.pr, v.pi - run.pi, v.e1 - run.e1, v.e2 - run.e2});
-  // (4) ... added to the thread's entries: S[i+1] = sum_{m <= i}
-  for (int i = lo_i; i < hi_i; ++i) S[i + 1] = acf_add(S[i + 1], off);
+  // (3) ... and the prefix table is written once: S[i+1] = sum_{m <= i}
+#pragma unroll
+  for (int j = 0; j < EMAX; ++j) {
+    const int i = lo_i + j;
+    if (j < E && i < m_cnt) S[i + 1] = acf_add(pre[j], off);
+  }
   __syncthreads();
   for (int i = tid; i < n_here; i += ACF_THREADS) {
     const acf4 hi = S[i + W], lo = S[i];
