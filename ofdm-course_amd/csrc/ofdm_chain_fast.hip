@@ -439,9 +439,20 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
         for (int q = 0; q < taps; ++q) {
           const int idx = sh_tidx[q];
           const c64 x = sh_tx[q];                       // zero for unused / overwritten slots
-          const cx<T> w = P.tw[(int)(((int64_t)(idx < 0 ? 0 : idx) * kk[t]) & (N - 1))];
-          hr += x.x * (double)w.x - x.y * (double)w.y;
-          hi += x.x * (double)w.y + x.y * (double)w.x;
+          // W_N^(idx k) computed, not looked up: the table gather (64 addresses of stride 4 idx per wave-instruction,
+          // one dependent round trip per tap) made this prologue 12 % of a frame's latency (in-kernel stamps); the
+          // exponent is reduced exactly in integers, so the sine / cosine see an exact argument
+          const int e = (int)(((int64_t)(idx < 0 ? 0 : idx) * kk[t]) & (N - 1));
+          T ws, wc;
+          if constexpr (sizeof(T) == 4) {                     // v_sin_f32 / v_cos_f32 take the angle in turns; |error| ~ 1e-6
+            const float turns = (float)e * (1.0f / (float)N);
+            ws = __builtin_amdgcn_sinf(turns);
+            wc = __builtin_amdgcn_cosf(turns);
+          } else {
+            sincospi((double)(2 * e) * (1.0 / (double)N), &ws, &wc);
+          }
+          hr += x.x * (double)wc + x.y * (double)ws;       // w = (wc, -ws)
+          hi += x.y * (double)wc - x.x * (double)ws;
         }
         const cx<T> H = mk<T>((T)hr, (T)hi);
         if (h_out) h_out[f * P.n_carrier + kk[t]] = H;
