@@ -165,6 +165,16 @@ int ofdm_BER_func(const uint8_t* bit_tx, const uint8_t* bit_rx, int64_t n, int64
 /* T5/MER_func.m:1-26. */
 int ofdm_MER_func(const void* iq, int64_t n, const char* constellation, double* mer_db_out, int flags);
 
+/* ---- PAPR study of Task 2 (T2/Main_model_Task_2.m:69-82) ------------------------------------- */
+/* T2/calculatePAPR.m:2-11: *papr_db_out = 10 log10(max|x|^2 / mean|x|^2) (HOST scalar). */
+int ofdm_calculatePAPR(const void* x, int64_t n, double* papr_db_out, int flags);
+/* T2/calculate_window_PAPR.m:2-15: paprs_out[i] = PAPR of x(i : i+Nfft-1), i < n - nfft + 1 (double whatever the
+ * input precision; nothing is written when n < nfft).  O(1) per window (sliding maximum + prefix sums), nfft <= 8192. */
+int ofdm_calculate_window_PAPR(const void* x, int64_t n, int nfft, double* paprs_out, int flags);
+/* T2/calculateCCDF.m:2-6 ([CCDF, x] = ecdf(values); CCDF = 1 - CCDF): sorted distinct values with the smallest one
+ * repeated in front, NaN ignored.  Outputs hold up to n + 1 doubles; *n_out (HOST) = entries written. */
+int ofdm_calculateCCDF(const double* papr_values, int64_t n, double* papr_ccdf_out, double* ccdf_out, int64_t* n_out, int flags);
+
 /* ---- fused Task-5 RX chain (the benchmark path; everything stays in HBM) -------------------- */
 /* Per frame of n_symb symbols (call order of T5/Task5_part2.m:169-193,:272,:279-303 with the
  * sensing matrix of T5/Main_model_Task_5.m:182-190):

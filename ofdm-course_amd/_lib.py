@@ -62,6 +62,9 @@ SIGNATURES = {
     "ofdm_OMP_estimate": [_vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _pi, _i],
     "ofdm_BER_func": [_vp, _vp, _i64, _pi64, _i],
     "ofdm_MER_func": [_vp, _i64, _cp, _pd, _i],
+    "ofdm_calculatePAPR": [_vp, _i64, _pd, _i],
+    "ofdm_calculate_window_PAPR": [_vp, _i64, _i, _vp, _i],
+    "ofdm_calculateCCDF": [_vp, _i64, _vp, _vp, _pi64, _i],
     "ofdm_rx_plan_create": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _cp, _i],
     "ofdm_rx_plan_destroy": [_vp],
     "ofdm_rx_plan_set_mmse": [_vp, _vp, _i64, _d, _i],

@@ -35,7 +35,7 @@ __all__ = [
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
     "add_CFO", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
-    "MER_func", "RxPlan", "rx_chain_task5", "rx_chain_task4", "DEFAULT_REGISTER",
+    "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "DEFAULT_REGISTER",
 ]
 
 DEFAULT_REGISTER = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)   # T5/Main_model_Task_5.m:55
@@ -572,6 +572,42 @@ def MER_func(IQ_RX, Constellation):
     mer = C.c_double(0)
     L.check(call.lib.ofdm_MER_func(call.cin(IQ_RX), n, _cstr(Constellation), C.byref(mer), call.flags), "MER_func")
     return mer.value
+
+
+# ------------------------------------------------------------------------------------------------
+# PAPR study (Task 2)
+# ------------------------------------------------------------------------------------------------
+
+def calculatePAPR(OFDM_signal):
+    """T2/calculatePAPR.m:2-11 -> PAPR in dB (host scalar)."""
+    call = _Call(OFDM_signal)
+    n = int(np.prod(tuple(OFDM_signal.shape)))
+    v = C.c_double(0)
+    L.check(call.lib.ofdm_calculatePAPR(call.cin(OFDM_signal), n, C.byref(v), call.flags), "calculatePAPR")
+    return v.value
+
+
+def calculate_window_PAPR(Tx_OFDM_Signal, Nfft):
+    """T2/calculate_window_PAPR.m:2-15 -> PAPRs row (float64, length(signal) - Nfft + 1 entries)."""
+    call = _Call(Tx_OFDM_Signal)
+    n = int(np.prod(tuple(Tx_OFDM_Signal.shape)))
+    n_out = max(n - int(Nfft) + 1, 0)
+    out, pout = call._out((n_out,), np.float64, torch.float64 if call.dev else None)
+    L.check(call.lib.ofdm_calculate_window_PAPR(call.cin(Tx_OFDM_Signal), n, int(Nfft), pout, call.flags),
+            "calculate_window_PAPR")
+    return out
+
+
+def calculateCCDF(PAPR_values):
+    """T2/calculateCCDF.m:2-6 -> (PAPR_ccdf, CCDF): ecdf abscissae (smallest value twice) and 1 - F."""
+    call = _Call(PAPR_values, f64=True)
+    n = int(np.prod(tuple(PAPR_values.shape)))
+    pv = call._flat(PAPR_values, np.float64, torch.float64 if call.dev else None)[0]
+    x, px = call._out((n + 1,), np.float64, torch.float64 if call.dev else None)
+    c, pc = call._out((n + 1,), np.float64, torch.float64 if call.dev else None)
+    n_out = C.c_int64(0)
+    L.check(call.lib.ofdm_calculateCCDF(pv, n, px, pc, C.byref(n_out), call.flags), "calculateCCDF")
+    return x[: n_out.value], c[: n_out.value]
 
 
 # ------------------------------------------------------------------------------------------------

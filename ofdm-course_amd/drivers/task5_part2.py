@@ -24,15 +24,34 @@ def scenario_combs(N_carrier=1024, lo=4, hi=256):
     return combs, N_carrier // combs
 
 
+def random_pilot_layout(Nfft, N_carrier, amount_pilots, seed):
+    """:58-64 -- `sort(randperm(N_carrier, Np))` and `pilot_step = pilotCarriers(3) - pilotCarriers(2)`; a step of 1
+    switches to the 100 % rule like the regular mask (:67-75).  The draw is PCG64(seed) (MATLAB's `randperm` stream
+    is not restated: any sorted subset without repetition is a valid mask).  Returns the layout and pilot_step."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pilotCarriers = np.sort(rng.permutation(N_carrier)[:int(amount_pilots)] + 1).astype(np.float64)
+    pilot_step = int(pilotCarriers[2] - pilotCarriers[1])
+    if pilot_step == 1:
+        return c.layout_percent(Nfft, N_carrier, 100, tail=1) + (1,)
+    allCarriers = np.arange(1, Nfft + 1, dtype=np.float64)
+    dataCarriers = allCarriers[:N_carrier][~np.isin(allCarriers[:N_carrier], pilotCarriers)]
+    return allCarriers, pilotCarriers, dataCarriers, pilot_step
+
+
 def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_SpF=7, Constellation="16QAM",
-        monteCarloRuns=100, SNR_dB=20, combs=None, DelayProfile="EPA", SamplingRate=4e7, seed=5, rank=0, world=1):
-    """T5/Task5_part2.m:4-320 with reg_pilot = 1 (:12)."""
+        monteCarloRuns=100, SNR_dB=20, combs=None, DelayProfile="EPA", SamplingRate=4e7, seed=5, rank=0, world=1,
+        reg_pilot=1, Nps=None):
+    """T5/Task5_part2.m:4-320.  reg_pilot = 1 (:12): one scenario per comb; reg_pilot = 0: one scenario per pilot
+    count `Nps` (:21, default = the regular study's counts) on a random mask, dictionary = all Nfft delays (:181-184)."""
     lib = lib or c.default_lib()
     T_Guard = Nfft // 8
     N_symb = Amount_OFDM_Frames * Amount_ODFM_SpF
     if combs is None:
         combs, _ = scenario_combs(N_carrier)
     combs = np.asarray(combs, dtype=int)
+    if not reg_pilot:
+        Nps = np.asarray(N_carrier // combs if Nps is None else Nps, dtype=int)
+        combs = np.zeros(len(Nps), dtype=int)                                       # scenario axis = pilot counts (:42-44)
     rng = np.random.Generator(np.random.PCG64(seed))                                # :23 rng(5)
     channel_Seeds = rng.integers(1, 2 ** 16 + 1, size=(len(combs), monteCarloRuns))  # :24
     dict_, bps = lib.constellation_func(Constellation)
@@ -42,7 +61,12 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
     bit_sum = np.zeros(len(combs), dtype=np.int64)
     runs = np.zeros(len(combs), dtype=np.int64)
     for kk, comb in enumerate(combs):                                               # :46
-        allCarriers, pilotCarriers, dataCarriers = c.layout_comb(Nfft, N_carrier, int(comb))    # :48-79
+        if reg_pilot:
+            allCarriers, pilotCarriers, dataCarriers = c.layout_comb(Nfft, N_carrier, int(comb))    # :48-79
+            K = int(np.ceil(Nfft / comb))                                           # :183
+        else:
+            allCarriers, pilotCarriers, dataCarriers, _ = random_pilot_layout(Nfft, N_carrier, Nps[kk], [seed, 7, kk])
+            K = Nfft                                                                # :181 F = dftmtx(Nfft), all columns
         pilotValues = c.alternating_pilots(amp_pilots, len(pilotCarriers), N_symb)  # :86-91
         Size_Buffer = N_symb * len(dataCarriers) * bps
         input_bits = c.synthetic_bits(Size_Buffer, [seed, kk])                      # :96 (scrambler commented out, :99-115)
@@ -50,7 +74,6 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
         X = lib.OFDM_map_carriers(TX_IQ, N_symb, Nfft, dataCarriers, pilotCarriers, pilotValues)   # :123
         Tx = np.asarray(lib.OFDM_modulator(X, T_Guard)).ravel(order="F")            # :130-132
         Tx_noised, _ = lib.Noise(SNR_dB, Tx, seed=seed, stream=kk)                  # :134 (noise BEFORE the channel)
-        K = int(np.ceil(Nfft / comb))                                               # :184
         S = lib.sensing_matrix(pilotCarriers, Nfft, K)                              # :181-189 closed form
         for jj in range(monteCarloRuns):                                            # :148
             if (kk * monteCarloRuns + jj) % world != rank:
@@ -77,7 +100,8 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
             bit_sum[kk] += input_bits.size
             runs[kk] += 1
     safe = np.maximum(runs, 1)
-    return {"driver": "Task 5/Task5_part2.m", "combs": combs, "amounts_pilots": N_carrier // combs,
+    return {"driver": "Task 5/Task5_part2.m", "reg_pilot": int(bool(reg_pilot)), "combs": combs,
+            "amounts_pilots": N_carrier // combs if reg_pilot else Nps,
             "estimators": list(ESTIMATORS), "monteCarloRuns": monteCarloRuns, "SNR_dB": SNR_dB,
             "NMSEs": nmse_sum / safe, "BERs": err_sum / np.maximum(bit_sum, 1),     # :309-318 (mean over jj)
             "_sums": {"nmse": nmse_sum, "errors": err_sum, "bits": bit_sum, "runs": runs}}

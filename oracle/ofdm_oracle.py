@@ -657,6 +657,46 @@ def MER_func(IQ_RX, Constellation):
 
 
 # ----------------------------------------------------------------------------
+# PAPR study of Task 2
+# ----------------------------------------------------------------------------
+
+def calculatePAPR(OFDM_signal):
+    """T2/calculatePAPR.m:2-11: 10 log10(max(abs(x))^2 / mean(abs(x).^2))."""
+    x = np.asarray(OFDM_signal, dtype=np.complex128).ravel(order="F")
+    a = np.abs(x)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(10 * np.log10(np.max(a) ** 2 / np.mean(a ** 2))) if x.size else float("nan")
+
+
+def calculate_window_PAPR(Tx_OFDM_Signal, Nfft):
+    """T2/calculate_window_PAPR.m:2-15: PAPR of every window x(i : i+Nfft-1), each recomputed from scratch."""
+    x = np.asarray(Tx_OFDM_Signal, dtype=np.complex128).ravel(order="F")
+    n_PAPRs = x.size - int(Nfft) + 1                                  # :4
+    if n_PAPRs <= 0:
+        return np.zeros(0)
+    a = np.abs(x)
+    w = np.lib.stride_tricks.sliding_window_view(a, int(Nfft))        # :8-13, one row per window
+    out = np.empty(n_PAPRs)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for i0 in range(0, n_PAPRs, 4096):                            # bounded temporaries
+            blk = w[i0:i0 + 4096]
+            out[i0:i0 + 4096] = 10 * np.log10(np.max(blk, axis=1) ** 2 / np.mean(blk ** 2, axis=1))
+    return out
+
+
+def calculateCCDF(PAPR_values):
+    """T2/calculateCCDF.m:2-6: [F, x] = ecdf(values) (NaN dropped; x = sorted distinct values with the first one
+    repeated, F = [0, cumulative fraction]) -> (PAPR_ccdf = x, CCDF = 1 - F)."""
+    v = np.asarray(PAPR_values, dtype=np.float64).ravel()
+    v = v[~np.isnan(v)]
+    if v.size == 0:
+        return np.zeros(0), np.zeros(0)
+    u, counts = np.unique(v + 0.0, return_counts=True)
+    F = np.concatenate([[0.0], np.cumsum(counts) / v.size])
+    return np.concatenate([[u[0]], u]), 1.0 - F
+
+
+# ----------------------------------------------------------------------------
 # pilot layouts of the drivers
 # ----------------------------------------------------------------------------
 

@@ -13,7 +13,8 @@ class OracleLib:
         for name in ("constellation_func", "mapping", "demapping", "OFDM_map_carriers", "get_payload",
                      "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "add_STO",
                      "add_CFO", "remove_IFO", "interpolate", "estimate_channel",
-                     "equalize_signal", "LS_CE", "sensing_matrix", "OMP_estimate", "MER_func"):
+                     "equalize_signal", "LS_CE", "sensing_matrix", "OMP_estimate", "MER_func",
+                     "calculatePAPR", "calculate_window_PAPR", "calculateCCDF"):
             setattr(self, name, getattr(oracle, name))
 
     def Scrambler(self, Register, sequence):

@@ -34,6 +34,21 @@ def test_layout_rules(drivers, oracle):
     assert len(set(amounts.tolist())) == 57
 
 
+def test_random_pilot_layout(drivers):
+    a, p, d, step = drivers.task5_part2.random_pilot_layout(512, 128, 16, [5, 7, 0])     # T5/Task5_part2.m:58-64
+    assert len(p) == 16 and np.all(np.diff(p) > 0) and p[0] >= 1 and p[-1] <= 128
+    assert len(d) == 128 - 16 and not np.intersect1d(p, d).size and step == int(p[2] - p[1])
+    _, p2, _, _ = drivers.task5_part2.random_pilot_layout(512, 128, 16, [5, 7, 0])
+    assert np.array_equal(p, p2)
+
+
+def test_task5_part2_random_pilots(drivers, olib):
+    r = drivers.task5_part2.run(olib, Nfft=512, N_carrier=128, Nps=[16, 32], reg_pilot=0, monteCarloRuns=2,
+                                SamplingRate=2e7)
+    assert r["reg_pilot"] == 0 and r["NMSEs"].shape == (4, 2) and np.all(np.isfinite(r["NMSEs"]))
+    assert r["NMSEs"][3, 1] < 0.05 and np.all(r["_sums"]["runs"] == 2)             # OMP on 32 random pilots
+
+
 def test_fading_taps(drivers):
     t = drivers.common.fading_taps("EPA", 4e7, 1234)
     assert np.isclose(np.sum(np.abs(t[:, 1]) ** 2), 1.0)

@@ -107,3 +107,25 @@ def test_task5_part2_subset(drivers, ofdm, olib):
     assert np.array_equal(g["_sums"]["errors"], o["_sums"]["errors"])
     np.testing.assert_allclose(g["NMSEs"], o["NMSEs"], rtol=1e-6)
     assert np.array_equal(g["amounts_pilots"], [256, 64, 16])
+
+
+def test_task5_part2_random_pilots(drivers, ofdm, olib):
+    """reg_pilot = 0 (T5/Task5_part2.m:57-64): random pilot masks, dictionary of all Nfft delays (:181-184)."""
+    kw = dict(Nfft=1024, N_carrier=256, Nps=[24, 64], reg_pilot=0, monteCarloRuns=2)
+    g = drivers.task5_part2.run(ofdm, **kw)
+    o = drivers.task5_part2.run(olib, **kw)
+    assert np.array_equal(g["_sums"]["errors"], o["_sums"]["errors"])
+    np.testing.assert_allclose(g["NMSEs"], o["NMSEs"], rtol=1e-6)
+    assert np.array_equal(g["amounts_pilots"], [24, 64]) and g["reg_pilot"] == 0
+
+
+def test_task2_papr_tables(drivers, ofdm, olib):
+    """T2/Main_model_Task_2.m:69-82 through the driver replay."""
+    kw = dict(Nfft=512, N_carrier=200, Amount_OFDM_Frames=3, Amount_ODFM_SpF=4)
+    g = drivers.task2.run(ofdm, **kw)
+    o = drivers.task2.run(olib, **kw)
+    for tag in ("plain", "scrambled"):
+        assert abs(g["papr"][tag]["PAPR_dB"] - o["papr"][tag]["PAPR_dB"]) < 1e-9
+        np.testing.assert_allclose(g["papr"][tag]["_PAPRs"], o["papr"][tag]["_PAPRs"], rtol=0, atol=1e-9)
+        assert g["papr"][tag]["CCDF"][0] == 1.0 and g["papr"][tag]["CCDF"][-1] == 0.0
+        assert np.all(np.diff(g["papr"][tag]["PAPR_ccdf"][1:]) > 0)

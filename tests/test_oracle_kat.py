@@ -142,3 +142,22 @@ def test_philox_reference_vector():
     r = o.philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32),
                         np.array([0xa4093822, 0x299f31d0], np.uint32))[0]
     assert [hex(int(v)) for v in r] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_papr_kat():
+    """Task 2 PAPR study: closed-form cases.  A constant-envelope signal has 0 dB; one sample of amplitude A among
+    N-1 unit samples has 10 log10(A^2 N / (A^2 + N - 1)); the window version is the scalar one window by window
+    (`calculate_window_PAPR.m:8-14`); ecdf of [3 1 2 2] is x = [1 1 2 3], F = [0 .25 .75 1] (`calculateCCDF.m:4-5`)."""
+    assert o.calculatePAPR(np.exp(1j * np.arange(64))) == pytest.approx(0.0, abs=1e-12)
+    x = np.ones(100, complex)
+    x[17] = 5j
+    assert o.calculatePAPR(x) == pytest.approx(10 * np.log10(25 * 100 / (25 + 99)), abs=1e-12)
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(400) + 1j * rng.standard_normal(400)
+    w = o.calculate_window_PAPR(y, 64)
+    assert w.shape == (337,)
+    for i in (0, 1, 100, 336):
+        assert w[i] == pytest.approx(o.calculatePAPR(y[i:i + 64]), abs=1e-12)
+    assert o.calculate_window_PAPR(y, 401).size == 0
+    xs, c = o.calculateCCDF([3.0, 1.0, 2.0, 2.0, np.nan])
+    assert np.array_equal(xs, [1, 1, 2, 3]) and np.array_equal(c, [1, 0.75, 0.25, 0])
