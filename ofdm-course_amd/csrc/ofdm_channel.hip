@@ -67,13 +67,15 @@ __global__ void power_partial_kernel(const cx<T>* __restrict__ xall, int64_t len
   }
 }
 
-// out[0] = sqrt(NoisePower/2) (per-component sigma), out[1] = sqrt(NoisePower) (N_var of Noise.m:11)
-__global__ void noise_sigma_kernel(const double* __restrict__ partial, int n_part, int64_t len, double snr_lin,
-                                   double* __restrict__ out, int64_t n_frames) {
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < n_frames) {
-    double s = 0;
-    for (int i = 0; i < n_part; ++i) s += partial[f * n_part + i];
+// out[0] = sqrt(NoisePower/2) (per-component sigma), out[1] = sqrt(NoisePower) (N_var of Noise.m:11).
+// One wavefront per frame (a single thread walking 2048 partial sums cost more than the noise pass it feeds).
+__global__ __launch_bounds__(64) void noise_sigma_kernel(const double* __restrict__ partial, int n_part, int64_t len, double snr_lin,
+                                                         double* __restrict__ out, int64_t n_frames) {
+  const int64_t f = blockIdx.x;
+  double s = 0;
+  for (int i = threadIdx.x; i < n_part; i += 64) s += partial[f * n_part + i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) {
     const double p = s / (double)len;             // Noise.m:3
     const double np = p / snr_lin;                // :5
     out[2 * f] = sqrt(np / 2.0);
@@ -287,7 +289,7 @@ static int noise_common(double snr_db, const void* x, int64_t len, int64_t n_fra
   if (f64) hipLaunchKernelGGL(power_partial_kernel<double>, pgrid, dim3(256), 0, ctx().stream, (const c64*)dx, len, (double*)dpart);
   else hipLaunchKernelGGL(power_partial_kernel<float>, pgrid, dim3(256), 0, ctx().stream, (const c32*)dx, len, (double*)dpart);
   OFDM_TRY(check_launch("power_partial_kernel"));
-  hipLaunchKernelGGL(noise_sigma_kernel, dim3(cdiv_u(n_frames, 64)), dim3(64), 0, ctx().stream, (const double*)dpart,
+  hipLaunchKernelGGL(noise_sigma_kernel, dim3((unsigned)n_frames), dim3(64), 0, ctx().stream, (const double*)dpart,
                      (int)bpf, len, snr_lin, (double*)dsig, n_frames);
   OFDM_TRY(check_launch("noise_sigma_kernel"));
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

@@ -141,10 +141,17 @@ __global__ void window_papr_reg_kernel(const cx<T>* __restrict__ x, int64_t n, i
   double* const M = a;                                // [2][wp]
   double* const S = TWO_PHASE ? a : a + 2 * wp;       // [2][wp]
   const int64_t base = (int64_t)blockIdx.x * W;
-  for (int j = tid; j < 2 * W; j += nt) {
-    const int64_t g = base + j;
+  cx<T> xv[C];                                        // all C loads of a thread in flight together
+#pragma unroll
+  for (int e = 0; e < C; ++e) {
+    const int64_t g = base + tid + e * nt;
+    xv[e] = g < n ? x[g] : mk<T>(0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < C; ++e) {
+    const int j = tid + e * nt;
     const int b = j >= W, q = b ? j - W : W - 1 - j;
-    M[b * wp + lds_pad(q)] = g < n ? power_of(x[g]) : 0.0;
+    M[b * wp + lds_pad(q)] = power_of(xv[e]);
   }
   __syncthreads();
   double m[C], s[C];
