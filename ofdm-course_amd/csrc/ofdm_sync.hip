@@ -40,9 +40,13 @@ __device__ __forceinline__ acf4 acf_shfl_up(acf4 v, int d) {
 
 template <typename T>
 __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
-                                                          cx<T>* __restrict__ rho, int64_t n_out) {
-  x += (int64_t)blockIdx.y * len;                    // grid.y = frame (one stream per frame, batched callers)
-  rho += (int64_t)blockIdx.y * n_out;
+                                                          cx<T>* __restrict__ rho, int64_t n_out, int64_t rho_stride = 0,
+                                                          const int64_t* __restrict__ resolved = nullptr) {
+  // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out); frames whose
+  // plateau search already succeeded on a prefix (resolved[2 f + 1] != 0) are skipped
+  if (resolved && resolved[2 * blockIdx.y + 1]) return;
+  x += (int64_t)blockIdx.y * len;
+  rho += (int64_t)blockIdx.y * (rho_stride ? rho_stride : n_out);
   __shared__ acf4 S[ACF_ELEMS + 1];                  // exclusive prefix: S[i] = sum_{m<i}
   __shared__ acf4 wtot[ACF_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -123,10 +127,12 @@ __device__ int64_t first_index_where(const cx<T>* __restrict__ rho, int64_t from
 template <typename T>
 __global__ __launch_bounds__(PLAT_THREADS) void acf_plateau_kernel(const cx<T>* __restrict__ rho, int64_t n, int W,
                                                                    double thr, int64_t* __restrict__ out,
-                                                                   double* __restrict__ outv) {
-  rho += (int64_t)blockIdx.x * n;                    // grid.x = frame
+                                                                   double* __restrict__ outv, int64_t rho_stride = 0,
+                                                                   int skip_resolved = 0) {
+  rho += (int64_t)blockIdx.x * (rho_stride ? rho_stride : n);   // grid.x = frame
   out += 2 * blockIdx.x;
   outv += 2 * blockIdx.x;
+  if (skip_resolved && out[1]) return;               // decided on a prefix of rho: the full scan finds the same runs
   __shared__ int64_t sh;
   auto above = [thr](cx<T> v) { return sqrt((double)v.x * v.x + (double)v.y * v.y) > thr; };
   auto below = [thr](cx<T> v) { return !(sqrt((double)v.x * v.x + (double)v.y * v.y) > thr); };
@@ -476,8 +482,23 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t i = (int64_t)sy * sym_len + t_guard + slot_m(e);
-        v[e] = t4_rotate<T>(v[e], c1, i, inv);
-        if (fi > 0) v[e] = t4_rotate<T>(v[e], -(double)fi, i, inv);
+        if constexpr (std::is_same<T, float>::value) {
+          // throughput mode: add_CFO(-FreqOffset) and remove_IFO's rotation as ONE rotation -- the fractional part of the
+          // phase in double, the integer-offset part reduced exactly in integers (N is a power of two), sine / cosine
+          // in float; parity mode below keeps the reference's two roundings
+          double t = c1 * (double)i * inv;
+          t -= floor(t);
+          if (fi > 0) {
+            t -= (double)(((int64_t)fi * i) & (N - 1)) * inv;
+            t += t < 0.0 ? 1.0 : 0.0;
+          }
+          float sn, cs;
+          sincospif(2.0f * (float)t, &sn, &cs);
+          v[e] = mk<T>(v[e].x * cs - v[e].y * sn, v[e].x * sn + v[e].y * cs);
+        } else {
+          v[e] = t4_rotate<T>(v[e], c1, i, inv);
+          if (fi > 0) v[e] = t4_rotate<T>(v[e], -(double)fi, i, inv);
+        }
       }
     }
     if constexpr (NW > 1) {
@@ -604,10 +625,22 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   if (sync) {
     OFDM_ARG(n_out > 0 && Tg >= 1 && Tg <= ACF_MAXW, "rx_chain_task4: frame shorter than T_guard + Nfft, or T_guard outside 1..%d", ACF_MAXW);
     drho = arena + o_rho;
+    // The receiver only needs TgPosition and rho(TgPosition), and AutoCorrFunction.m:10-24 decides them on the first
+    // run above the threshold, its end and the first later sample above it: a prefix of three symbols settles nearly
+    // every frame.  Prefix = whole tiles, so its rho values are bit-identical to the full computation; frames it does
+    // not settle (ok = 0) are redone over the whole stream, the others leave that second pass at its first instruction.
+    const int64_t n_pref = std::min<int64_t>(n_out, ((3 * (int64_t)(N + Tg) + ACF_TILE - 1) / ACF_TILE) * ACF_TILE);
+    const bool two_pass = n_pref < n_out && !getenv("OFDM_T4_FULL_ACF");
+    if (two_pass) {
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_pref, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
+                         N, (cx<T>*)drho, n_pref, n_out, (const int64_t*)nullptr);
+      hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_pref, Tg, 0.77,
+                         (int64_t*)dres, (double*)dresv, n_out, 0);
+    }
     hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
-                       N, (cx<T>*)drho, n_out);
+                       N, (cx<T>*)drho, n_out, n_out, two_pass ? (const int64_t*)dres : (const int64_t*)nullptr);
     hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
-                       (int64_t*)dres, (double*)dresv);
+                       (int64_t*)dres, (double*)dresv, n_out, two_pass ? 1 : 0);
     hipLaunchKernelGGL(t4_scalars_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, (const double*)dresv, n_out,
                        dtg, dfo, dstat, F);
     OFDM_TRY(check_launch("AutoCorrFunction stage"));

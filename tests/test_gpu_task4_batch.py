@@ -140,3 +140,37 @@ def test_batch_against_oracle_replay(ofdm, oracle):
         assert np.count_nonzero(got_bits[f] != want) <= 2
         checked += 1
     assert checked >= 1
+
+
+@pytest.mark.parametrize("full_acf", [False, True])
+def test_batch_acf_prefix_and_full_scan(ofdm, monkeypatch, full_acf):
+    """The batched receiver searches the guard-interval plateau on a three-symbol prefix of the autocorrelation and
+    rescans the whole stream only for frames the prefix does not settle.  Frames: a normal one (settled on the prefix),
+    pure noise (never settled -> the reference's catch branch, TgPosition 65 + warning, AutoCorrFunction.m:21-24) and a
+    frame whose signal starts after the prefix (settled by the full scan).  All must equal the per-function entry,
+    which always computes the whole autocorrelation; OFDM_T4_FULL_ACF = the single-pass form."""
+    if full_acf:
+        monkeypatch.setenv("OFDM_T4_FULL_ACF", "1")
+    else:
+        monkeypatch.delenv("OFDM_T4_FULL_ACF", raising=False)
+    cfg_kw = dict(Nfft=1024, N_carrier=400, N_symb=12, const="16QAM")
+    d = _frames(ofdm, cfg_kw, 3, "fp64", seed=5)
+    rng = np.random.default_rng(9)
+    L = d["rx"].shape[0]
+    noise = lambda n: 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    d["rx"][:, 1] = noise(L)
+    late = 5 * (1024 + d["Tg"]) + 77                                     # beyond the 3-symbol prefix (4096 positions)
+    d["rx"][:, 2] = np.concatenate([noise(late), d["rx"][:L - late, 2]])
+    K = int(np.ceil(cfg_kw["N_carrier"] / 6))
+    plan = ofdm.RxPlan(1024, d["Tg"], 12, 400, d["pil"], d["dat"], d["col"], K, 3, "16QAM", precision="fp64")
+    out = ofdm.rx_chain_task4(plan, d["rx"], 1, 1, 1)
+    import warnings
+    for f in range(3):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            _, pos, fo = ofdm.AutoCorrFunction(d["rx"][:, f].copy(), d["Tg"], 1024)
+        assert int(out["TgPosition"][f]) == pos, f
+        assert abs(float(out["FreqOffset"][f]) - fo) < 1e-12 or (np.isnan(fo) and np.isnan(float(out["FreqOffset"][f])))
+        if w:
+            assert pos == 65 and int(out["status"][f]) != 0
+    assert int(out["TgPosition"][1]) == 65 and int(out["TgPosition"][2]) > 4096
