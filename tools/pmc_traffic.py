@@ -1,9 +1,10 @@
 """HBM bytes per launch of the chain kernels from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc.sh.
-usage: python tools/pmc_traffic.py <pmc-dir> > profiles/roundN/traffic.json
+usage: python tools/pmc_traffic.py <pmc-dir> [frames-per-step] > profiles/roundN/traffic.json
 FETCH_SIZE / WRITE_SIZE are in KB (1024 B); FETCH_SIZE is doubled (gfx950 counts half of wide streaming reads,
 MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import collections, csv, glob, json, sys
 d = sys.argv[1]
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20480      # bench.py default
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(d + "/tcc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(fn)):
@@ -18,6 +19,7 @@ for k, v in acc.items():
     out[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b}
     tot += b
 out["chain_bytes_per_step"] = tot
+out["frames"] = frames
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh) of `bench.py --no-cpu`, "
-               "8192 frames of config M fp32; FETCH_SIZE doubled for gfx950; unit KB = 1024 B")
+               "%d frames of config M fp32;" % frames + " FETCH_SIZE doubled for gfx950; unit KB = 1024 B")
 print(json.dumps(out, indent=1))
