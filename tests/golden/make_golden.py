@@ -124,5 +124,23 @@ def main():
             print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
 
 
+def papr_fixture():
+    """Task 2 PAPR study: an OFDM stream (Nfft 256, 16QAM, 12 symbols) -> whole-signal PAPR, window PAPR, CCDF."""
+    rng = np.random.default_rng(20240502)
+    nfft, nc, tg, ns = 256, 100, 32, 12
+    pc, dc = o.pilot_layout_percent(nfft, nc, 15, 2)
+    D, bps = o.constellation_func("16QAM")
+    iq, _ = o.mapping(rng.integers(0, 2, len(dc) * ns * bps), "16QAM")
+    tx = o.OFDM_modulator(o.OFDM_map_carriers(iq, ns, nfft, dc, pc, 2 * np.max(np.abs(D))), tg).ravel(order="F")
+    paprs = o.calculate_window_PAPR(tx, nfft)
+    x, c = o.calculateCCDF(np.round(paprs, 3))                     # rounded: ties, like a histogram of the curve
+    np.savez_compressed(os.path.join(HERE, "papr.npz"), tx=tx, nfft=nfft, papr=o.calculatePAPR(tx), paprs=paprs,
+                        ccdf_in=np.round(paprs, 3), ccdf_x=x, ccdf=c)
+
+
 if __name__ == "__main__":
-    main()
+    if "--papr-only" in sys.argv:
+        papr_fixture()
+    else:
+        main()
+        papr_fixture()

@@ -82,3 +82,13 @@ def test_task5_chain_fixture(ofdm, monkeypatch, path):
     assert np.array_equal(np.asarray(out["errors"]).astype(np.int64), g["errors"])
     assert np.array_equal(np.asarray(out["index"]).T, g["index"])
     assert rel_l2(np.asarray(out["H"]).T, g["H"]) < 1e-9
+
+
+def test_papr_fixture(ofdm):
+    """Task 2 PAPR study against the frozen oracle outputs: 1e-9 dB (sliding maximum exact, mean power from prefix
+    sums in double), CCDF exact."""
+    g = np.load(os.path.join(G, "papr.npz"))
+    assert abs(ofdm.calculatePAPR(g["tx"]) - float(g["papr"])) < 1e-9
+    np.testing.assert_allclose(np.asarray(ofdm.calculate_window_PAPR(g["tx"], int(g["nfft"]))), g["paprs"], rtol=0, atol=1e-9)
+    x, c = ofdm.calculateCCDF(g["ccdf_in"])
+    assert np.array_equal(np.asarray(x), g["ccdf_x"]) and np.array_equal(np.asarray(c), g["ccdf"])
