@@ -387,6 +387,70 @@ __device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
   else return demap_square<T, BA>(tab, z);
 }
 
+// Pack stage of a frame: decided symbols `codes` (one byte each, LDS, zero-padded to a multiple of 32) -> packed bits
+// (bit i of the frame -> byte i/8, bit 7 - i%8) + this thread's share of the BER numerator.  A group of 32 symbols is
+// exactly `bps` 32-bit words.  BPS > 0 (square QAM, bps known at compile time): every shift is a constant, the group's
+// reference words are requested before anything else and the stores leave at the end -- with a run-time bps the
+// compiler emitted store -> load -> s_waitcnt vmcnt(0) once per word, up to eight dependent HBM round trips per thread
+// (12 % of a frame's workgroup time in the in-kernel timestamps).  BPS = 0: run-time bps (any constellation).
+template <int BPS>
+__device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes, int n_codes, int bps_rt, int frame_words,
+                                               uint32_t* __restrict__ out_f, const uint32_t* __restrict__ ref_f, int tid,
+                                               int nthr) {
+  unsigned err = 0;
+  const int n_groups = (n_codes + 31) >> 5;
+  for (int grp = tid; grp < n_groups; grp += nthr) {
+    if constexpr (BPS > 0) {
+      const int w0 = grp * BPS;
+      uint32_t refw[BPS], word[BPS];
+#pragma unroll
+      for (int j = 0; j < BPS; ++j) refw[j] = (ref_f && w0 + j < frame_words) ? ref_f[w0 + j] : 0u;
+      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
+      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
+      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+      unsigned long long acc = 0;
+      int nb = 0, wi = 0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        acc = (acc << BPS) | ((cw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        nb += BPS;
+        if (nb >= 32) {
+          nb -= 32;
+          word[wi++] = __builtin_bswap32((uint32_t)(acc >> nb));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BPS; ++j) {
+        if (w0 + j < frame_words) {
+          if (out_f) out_f[w0 + j] = word[j];
+          if (ref_f) err += __popc(word[j] ^ refw[j]);
+        }
+      }
+    } else {
+      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
+      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
+      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+      unsigned long long acc = 0;
+      int nb = 0, w = grp * bps_rt;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        acc = (acc << bps_rt) | ((cw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        nb += bps_rt;
+        if (nb >= 32) {
+          nb -= 32;
+          const uint32_t wd = __builtin_bswap32((uint32_t)(acc >> nb));
+          if (w < frame_words) {
+            if (out_f) out_f[w] = wd;
+            if (ref_f) err += __popc(wd ^ ref_f[w]);
+          }
+          ++w;
+        }
+      }
+    }
+  }
+  return err;
+}
+
 // What the fast / split paths need to know about an RX plan (ofdm_chain.hip owns the plan)
 struct FastPlanView {
   int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64, frame_words;

@@ -374,8 +374,10 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
 // kernel 3: all symbols of a frame
 // ---------------------------------------------------------------------------------------------
 // HEXT: the channel estimate of every frame comes from P.h_in (MMSE mode) instead of the OMP taps.
+// (second launch bound = wavefronts per SIMD the register allocation must allow: 5 <-> 96 VGPRs, i.e. five resident
+// 256-thread workgroups per CU for the pruned Nfft <= 2048 instantiations, which is where the benchmark runs)
 template <typename T, int NW, bool PRUNE2, int BA, bool HEXT = false>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? (NW <= 4 ? 5 : 4) : 3) : 2) void rx_symbols_kernel(FastParams<T> P, const cx<T>* __restrict__ rx,
                                                              int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                              const uint32_t* __restrict__ ref_bits,
                                                              uint32_t* __restrict__ errors_out,
@@ -485,30 +487,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
     __syncthreads();
     // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
     //      symbols is exactly `bps` 32-bit words: two 16-byte LDS reads, then registers only.
-    unsigned int err = 0;
-    const int n_groups = (n_codes + 31) >> 5;
-    for (int grp = gid; grp < n_groups; grp += 64 * NW) {
-      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
-      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
-      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-      unsigned long long acc = 0;
-      int nb = 0, w = grp * bps;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const uint32_t code = (cw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-        acc = (acc << bps) | code;
-        nb += bps;
-        if (nb >= 32) {
-          nb -= 32;
-          const uint32_t word = __builtin_bswap32((uint32_t)(acc >> nb));
-          if (w < P.frame_words) {
-            if (bits_out) bits_out[f * P.frame_words + w] = word;
-            if (ref_bits) err += __popc(word ^ ref_bits[f * P.frame_words + w]);
-          }
-          ++w;
-        }
-      }
-    }
+    const unsigned int err = pack_frame<2 * BA>(codes, n_codes, bps, P.frame_words,
+                                                bits_out ? bits_out + f * P.frame_words : nullptr,
+                                                ref_bits ? ref_bits + f * P.frame_words : nullptr, gid, 64 * NW);
     (void)frame_bits;
     if (ref_bits && errors_out) {
       if (err) atomicAdd(&sh_err, err);

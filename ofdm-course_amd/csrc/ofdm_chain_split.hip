@@ -152,29 +152,9 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
             }
       }
     __syncthreads();
-    unsigned int err = 0;
-    for (int grp = gid; grp < n_groups; grp += 256) {
-      const uint4 ca = *reinterpret_cast<const uint4*>(codes + 32 * grp);
-      const uint4 cb = *reinterpret_cast<const uint4*>(codes + 32 * grp + 16);
-      const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-      unsigned long long acc = 0;
-      int nb = 0, w = grp * bps;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const uint32_t code = (cw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-        acc = (acc << bps) | code;
-        nb += bps;
-        if (nb >= 32) {
-          nb -= 32;
-          const uint32_t word = __builtin_bswap32((uint32_t)(acc >> nb));
-          if (w < P.frame_words) {
-            if (bits_out) bits_out[f * P.frame_words + w] = word;
-            if (ref_bits) err += __popc(word ^ ref_bits[f * P.frame_words + w]);
-          }
-          ++w;
-        }
-      }
-    }
+    const unsigned int err = pack_frame<2 * BA>(codes, n_codes, bps, P.frame_words,
+                                                bits_out ? bits_out + f * P.frame_words : nullptr,
+                                                ref_bits ? ref_bits + f * P.frame_words : nullptr, gid, 256);
     if (ref_bits && errors_out) {
       if (err) atomicAdd(&sh_err, err);
       __syncthreads();
