@@ -155,13 +155,13 @@ __device__ __forceinline__ void frame_load(cx<T> (&v)[8], const cx<T>* __restric
                                            int gid, int lane) {
   if constexpr (NW == 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[lane + 64 * e];
+    for (int e = 0; e < 8; ++e) v[e] = nt_load(src + lane + 64 * e);
   } else {
     constexpr int BPT = 8 / NW;
 #pragma unroll
     for (int t = 0; t < NW; ++t)
 #pragma unroll
-      for (int b = 0; b < BPT; ++b) v[b * NW + t] = src[gid * BPT + b + 512 * t];
+      for (int b = 0; b < BPT; ++b) v[b * NW + t] = nt_load(src + gid * BPT + b + 512 * t);
   }
 }
 

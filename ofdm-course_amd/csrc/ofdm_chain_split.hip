@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
         for (int v = 0; v < 2; ++v)
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? xf[(int64_t)(s0 + v) * x_stride + k0 + 256 * u] : mk<T>(0, 0);
+            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? nt_load(xf + (int64_t)(s0 + v) * x_stride + k0 + 256 * u) : mk<T>(0, 0);
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512) void demod_keep8192_kernel(const cx<T>* __rest
     const cx<T>* src = y + s * (int64_t)(8192 + t_guard) + t_guard;
     cx<T> a[8], b[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { a[t] = src[gid + 512 * t]; b[t] = src[gid + 512 * t + 4096]; }
+    for (int t = 0; t < 8; ++t) { a[t] = nt_load(src + gid + 512 * t); b[t] = nt_load(src + gid + 512 * t + 4096); }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const cx<T> d = a[t] - b[t];

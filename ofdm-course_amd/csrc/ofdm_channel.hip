@@ -116,7 +116,7 @@ __global__ void awgn_kernel(const cx<T>* __restrict__ xall, cx<T>* __restrict__ 
     // the same realisation to ~1e-7 of a noise sample, at twice the rate (the double form made Noise compute-bound)
     const double u0 = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
     const double u1 = ((double)r[1] + 0.5) * 2.3283064365386963e-10;
-    const cx<T> v = x[i];
+    const cx<T> v = nt_load(x + i);                 // last reader of x (the power pass was the first)
     if constexpr (std::is_same<T, float>::value) {
       const float rad = sqrtf(-2.0f * logf((float)u0)) * (float)sg;
       float sn, cs;

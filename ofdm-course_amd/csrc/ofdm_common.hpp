@@ -50,6 +50,17 @@ template <typename T, bool INV> __host__ __device__ inline cx<T> mul_mi(cx<T> a)
   return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);
 }
 
+// Streaming read of a sample that no later instruction of the launch touches again: nontemporal (`global_load ... nt`).
+// The received samples are 90 % of the chain's bytes and are read exactly once; with the default cache policy the symbol
+// kernel ran at 280 M symbols/s, with nt loads at 287 M (same box, three alternating pairs) -- MI355X_MICROARCH.md quotes
+// the same 3-5 % between default-policy and nt streams.  Neighbouring nt loads still merge into 16-byte instructions.
+template <typename T>
+__device__ __forceinline__ cx<T> nt_load(const cx<T>* __restrict__ p) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  const v2 q = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+  return mk<T>(q.x, q.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // error state
 // ---------------------------------------------------------------------------------------------

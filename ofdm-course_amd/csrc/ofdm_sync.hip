@@ -397,9 +397,9 @@ __global__ void t4_ifo_kernel(cx<T>* __restrict__ y, int64_t len, int nfft, cons
 template <typename T>
 __device__ __forceinline__ cx<T> t4_raw(const cx<T>* __restrict__ x, int64_t i, int64_t len, int sym_len, int time_desync,
                                         int64_t pos) {
-  if (!time_desync) return x[i];
+  if (!time_desync) return nt_load(x + i);
   const int64_t i1 = i - sym_len;
-  return (i1 >= 0 && i1 < len - pos && i1 + pos < len) ? x[i1 + pos] : mk<T>(0, 0);
+  return (i1 >= 0 && i1 < len - pos && i1 + pos < len) ? nt_load(x + i1 + pos) : mk<T>(0, 0);
 }
 template <typename T>
 __device__ __forceinline__ cx<T> t4_rotate(cx<T> v, double cfo, int64_t i, double inv_nfft) {
