@@ -24,6 +24,26 @@ __global__ __launch_bounds__(256) void read_frames(const float4* __restrict__ x,
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+// the same frame walk with nontemporal loads (global_load_dwordx4 ... nt)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_frames_nt(const v4f* __restrict__ x, float* out, long n_frames, int sym_f4,
+                                                      int guard_f4, int n_symb) {
+  v4f acc = {0, 0, 0, 0};
+  const long frame_f4 = (long)(sym_f4 + guard_f4) * n_symb;
+  for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    const v4f* p = x + f * frame_f4;
+    for (int s = 0; s < n_symb; ++s) {
+      const v4f* q = p + (long)s * (sym_f4 + guard_f4) + guard_f4;
+      for (int i = threadIdx.x; i < sym_f4; i += 256 * 4) {
+        const v4f a = __builtin_nontemporal_load(q + i), b = __builtin_nontemporal_load(q + i + 256);
+        const v4f c = __builtin_nontemporal_load(q + i + 512), d = __builtin_nontemporal_load(q + i + 768);
+        acc += a + b + c + d;
+      }
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
 __global__ __launch_bounds__(256) void read_flat(const float4* __restrict__ x, float* out, long n_f4) {
   float4 acc = {0, 0, 0, 0};
   const long stride = (long)gridDim.x * 256 * 4;
@@ -58,6 +78,17 @@ int main() {
       const double rd = (double)n_frames * n_symb * sf4 * 16;
       printf("frames wg/cu=%d skip_guard=%d: %.1f us/launch, %.0f GB/s\n", wg_per_cu, guard, ms * 100, rd / (ms / 10 * 1e-3) / 1e9);
     }
+  }
+  for (int wg_per_cu : {4, 5, 8}) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(a);
+      for (int it = 0; it < 10; ++it)
+        hipLaunchKernelGGL(read_frames_nt, dim3(256 * wg_per_cu), dim3(256), 0, 0, (const v4f*)x, out, n_frames, sym_f4, guard_f4, n_symb);
+      hipEventRecord(b); hipEventSynchronize(b);
+    }
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double rd = (double)n_frames * n_symb * sym_f4 * 16;
+    printf("frames nt wg/cu=%d skip_guard=1: %.1f us/launch, %.0f GB/s\n", wg_per_cu, ms * 100, rd / (ms / 10 * 1e-3) / 1e9);
   }
   for (int wg_per_cu : {4, 8, 16}) {
     for (int rep = 0; rep < 2; ++rep) {
