@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void demod_keep8192_kernel(const cx<T>* __rest
       __syncthreads();
       cx<T>* dst = x + s * (int64_t)n_keep + base;
       const int cnt = n_keep - base < NW * WAVE_LDS_ELEMS ? n_keep - base : NW * WAVE_LDS_ELEMS;
-      for (int i = gid; i < cnt; i += 512) dst[i] = lwv[i];
+      for (int i = gid; i < cnt; i += 512) nt_store(dst + i, lwv[i]);
       if (base + NW * WAVE_LDS_ELEMS < n_keep) __syncthreads();
     }
   }

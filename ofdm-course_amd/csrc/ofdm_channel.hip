@@ -121,12 +121,12 @@ __global__ void awgn_kernel(const cx<T>* __restrict__ xall, cx<T>* __restrict__ 
       const float rad = sqrtf(-2.0f * logf((float)u0)) * (float)sg;
       float sn, cs;
       sincospif((float)(2.0 * u1), &sn, &cs);
-      y[i] = mk<T>(v.x + rad * cs, v.y + rad * sn);
+      nt_store(y + i, mk<T>(v.x + rad * cs, v.y + rad * sn));
     } else {
       const double rad = sqrt(-2.0 * log(u0));
       double sn, cs;
       sincospi(2.0 * u1, &sn, &cs);
-      y[i] = mk<T>((T)((double)v.x + sg * rad * cs), (T)((double)v.y + sg * rad * sn));
+      nt_store(y + i, mk<T>((T)((double)v.x + sg * rad * cs), (T)((double)v.y + sg * rad * sn)));
     }
   }
 }

@@ -61,6 +61,14 @@ __device__ __forceinline__ cx<T> nt_load(const cx<T>* __restrict__ p) {
   return mk<T>(q.x, q.y);
 }
 
+template <typename T>
+__device__ __forceinline__ void nt_store(cx<T>* __restrict__ p, cx<T> v) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  v2 q;
+  q.x = v.x; q.y = v.y;
+  __builtin_nontemporal_store(q, reinterpret_cast<v2*>(p));
+}
+
 // ---------------------------------------------------------------------------------------------
 // error state
 // ---------------------------------------------------------------------------------------------

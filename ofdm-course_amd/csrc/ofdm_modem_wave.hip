@@ -52,12 +52,12 @@ __global__ __launch_bounds__(64 * NW) void modem_wave_kernel(const cx<T>* __rest
       lwv[NW * (lane + 64 * t) + wave] = r;                    // bin k = NW (lane + 64 t) + wave
     }
     __syncthreads();
-    cx<T>* dst = out + s * out_stride;
+    cx<T>* dst = out + s * out_stride;                         // written once, read by a later launch: nontemporal stores
     if constexpr (MOD) {
-      for (int i = gid; i < N + t_guard; i += 64 * NW) dst[i] = lwv[i < t_guard ? N - t_guard + i : i - t_guard];   // :8-9
+      for (int i = gid; i < N + t_guard; i += 64 * NW) nt_store(dst + i, lwv[i < t_guard ? N - t_guard + i : i - t_guard]);   // :8-9
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dst[gid + 64 * NW * e] = lwv[gid + 64 * NW * e];
+      for (int e = 0; e < 8; ++e) nt_store(dst + gid + 64 * NW * e, lwv[gid + 64 * NW * e]);
     }
   }
 }

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
     __syncthreads();
     cx<T>* dst = X + sg * (int64_t)N;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[gid + 64 * NW * e] = lwv[gid + 64 * NW * e];
+    for (int e = 0; e < 8; ++e) nt_store(dst + gid + 64 * NW * e, lwv[gid + 64 * NW * e]);
   }
 }
 
