@@ -54,6 +54,17 @@ def synthetic_bits(Size_Buffer, seed):
     return np.random.Generator(np.random.PCG64(seed)).integers(0, 2, int(Size_Buffer), dtype=np.uint8)
 
 
+def payload_bits(Size_Buffer, seed, input_bits=None):
+    """`file_reader(File, Size_Buffer)` (file_reader.m:2-13): the caller's bits cut to Size_Buffer, else the
+    synthetic stand-in."""
+    if input_bits is None:
+        return synthetic_bits(Size_Buffer, seed)
+    b = np.asarray(input_bits, dtype=np.uint8).ravel()
+    if b.size < Size_Buffer:
+        raise ValueError(f"payload has {b.size} bits, the driver needs {int(Size_Buffer)}")
+    return b[:int(Size_Buffer)].copy()
+
+
 def scramble_per_frame(lib, fn, bits, n_frames):
     """The per-frame register-reset loops (T2/Main_model_Task_2.m:40-50, :126-137): the frame slices
     are equal (Size_Buffer is a multiple of the frame length), so one batched call does all frames."""

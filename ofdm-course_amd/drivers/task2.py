@@ -9,15 +9,16 @@ from . import common as c
 
 
 def run(lib=None, Nfft=1024, N_carrier=400, Amount_OFDM_Frames=10, Amount_ODFM_SpF=5, Percent_pilot=1,
-        Constellation="16QAM", seed=1):
-    """T2/Main_model_Task_2.m:6-162."""
+        Constellation="16QAM", seed=1, input_bits=None):
+    """T2/Main_model_Task_2.m:6-162.  `input_bits`: the payload `file_reader` would return (:32; default = seeded
+    synthetic bits); at least Size_Buffer bits, the first Size_Buffer are used like `input_bits(1:Size_Buffer)`."""
     lib = lib or c.default_lib()
     T_Guard = Nfft // 8
     N_symb = Amount_OFDM_Frames * Amount_ODFM_SpF
     allCarriers, pilotCarriers, dataCarriers = c.layout_percent(Nfft, N_carrier, Percent_pilot, tail=2)   # :16-24
     dict_, bps = lib.constellation_func(Constellation)                             # :28
     Size_Buffer = N_symb * len(dataCarriers) * bps
-    input_bits = c.synthetic_bits(Size_Buffer, seed)                               # :32
+    input_bits = c.payload_bits(Size_Buffer, seed, input_bits)                     # :32
     sc_bits = c.scramble_per_frame(lib, "Scrambler", input_bits, Amount_OFDM_Frames)   # :36-51
     TX_IQ, _ = lib.mapping(input_bits, Constellation)                              # :53
     sc_TX_IQ, pad = lib.mapping(sc_bits, Constellation)                            # :54

@@ -496,16 +496,49 @@ def interpolate(H, pilot_loc, Nfft, method):
 # channel estimators / equaliser
 # ----------------------------------------------------------------------------
 
-def estimate_channel(rx_signal, allCarriers, pilotCarriers, pilotValues):
-    """T5/estimate_channel.m:1-9.  Returns (H_est over allCarriers, Hest_at_pilots)."""
+def interp1_v5cubic(x, y, xq):
+    """MATLAB `interp1(x, y, xq, 'cubic')` as of R2020b: cubic convolution (Keys, a = -1/2; the 'v5cubic' rule)
+    on uniformly spaced knots with the end points extended by y(-1) = 3y(0) - 3y(1) + y(2); NaN outside the
+    knots.  (Before R2020b 'cubic' meant pchip; the reference needs >= R2021b for int2bit, demapping.m:15.)
+    Only used for the interpolation-type table of Task 4/README.md:181-183."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    y = np.asarray(y).ravel()
+    xq = np.asarray(xq, dtype=np.float64).ravel()
+    h = x[1] - x[0]
+    if not np.allclose(np.diff(x), h):
+        raise ValueError("interp1 'cubic' (v5cubic) needs uniformly spaced knots")
+    ye = np.concatenate([[3 * y[0] - 3 * y[1] + y[2]], y, [3 * y[-1] - 3 * y[-2] + y[-3]]])
+    t = (xq - x[0]) / h
+    k = np.clip(np.floor(t).astype(np.int64), 0, x.size - 2)
+    s = t - k
+    w = ((-s ** 3 + 2 * s ** 2 - s) / 2, (3 * s ** 3 - 5 * s ** 2 + 2) / 2, (-3 * s ** 3 + 4 * s ** 2 + s) / 2,
+         (s ** 3 - s ** 2) / 2)
+    out = sum(w[i] * ye[k + i] for i in range(4))
+    out = np.asarray(out, dtype=np.result_type(y.dtype, np.float64))
+    out[(xq < x[0]) | (xq > x[-1])] = np.nan
+    return out
+
+
+def estimate_channel(rx_signal, allCarriers, pilotCarriers, pilotValues, method="spline"):
+    """T5/estimate_channel.m:1-9.  Returns (H_est over allCarriers, Hest_at_pilots).  `method` is the last
+    argument of the `interp1` call on :8 -- 'spline' as committed; 'linear' / 'cubic' are the edits behind the
+    table of Task 4/README.md:181-183 (linear: NaN outside the pilots like interp1; cubic: interp1_v5cubic)."""
     X = np.asarray(rx_signal)
     pc = _idx0(pilotCarriers)
     tx = np.asarray(pilotValues)
     if tx.ndim == 1:
         tx = tx[:, None]
     Hp = np.mean(X[pc, :] / tx, axis=1)                              # :6
-    H_est = interp1_spline(np.asarray(pilotCarriers, dtype=np.float64).ravel(), Hp,
-                           np.asarray(allCarriers, dtype=np.float64).ravel())   # :8
+    xk = np.asarray(pilotCarriers, dtype=np.float64).ravel()
+    xq = np.asarray(allCarriers, dtype=np.float64).ravel()
+    if method == "spline":
+        H_est = interp1_spline(xk, Hp, xq)                           # :8
+    elif method == "linear":
+        H_est = interp1_linear(xk, Hp, xq)
+    elif method == "cubic":
+        H_est = interp1_v5cubic(xk, Hp, xq)
+    else:
+        raise ValueError(method)
     return H_est, Hp
 
 
@@ -529,8 +562,12 @@ def LS_CE(Y, Xp, pilot_loc, N_carrier):
     return interpolate(LS_est, pilot_loc, N_carrier, "spline")       # :31
 
 
-def MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR):
-    """T5/MMSE_CE.m:1-39 (quirks kept: Nps*(K1-K2), df=1/N_carrier, re-interpolation :38)."""
+def MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR, df=None):
+    """T5/MMSE_CE.m:1-39 (quirks kept: Nps*(K1-K2), df=1/N_carrier, re-interpolation :38).
+
+    `df=None` is the committed file (`df = 1/N_carrier`, :25).  The comment on that line gives the textbook
+    form `1/(ts*Nfft)`; passing `df=1/Nfft` is the variant that reproduces the MMSE curve of the published
+    graph `Task 5/graphs/mse(snr), comb1.png` (tests/test_oracle_published.py)."""
     Y = np.asarray(Y)
     Xp = np.asarray(Xp)
     if Y.ndim == 1:
@@ -551,7 +588,8 @@ def MMSE_CE(Y, Xp, pilot_loc, Nfft, N_carrier, h, SNR):
     r = np.sum(tmp) / hh                                             # :22
     r2 = np.sum(tmp * k) / hh                                        # :23
     tau_rms = np.sqrt(r2 - r ** 2)                                   # :24
-    df = 1.0 / N_carrier                                             # :25
+    if df is None:
+        df = 1.0 / N_carrier                                         # :25
     j2pi_tau_df = 1j * 2 * np.pi * tau_rms * df                      # :26
     K1 = np.arange(N_carrier, dtype=np.float64)[:, None]
     K2 = np.arange(Np, dtype=np.float64)[None, :]
