@@ -25,7 +25,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -57,6 +56,60 @@ def cpu_baseline(cfg, rx_host, pilots, bits, seconds, n_threads):
                 errors=r["errors"])
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: this parent never touches the GPU (torch is not even imported
+    yet); it starts N fresh children -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment exactly as torch.distributed.run would set them -- relays rank 0's single JSON line and exits
+    non-zero if any child failed.  The Monte-Carlo loop the ranks share out is the `parfor`-able one of
+    Task5_part2.m:146-148."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    while any(c is None for c in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(c not in (None, 0) for c in rcs):          # a rank died: the others would wait in a collective for ever
+            time.sleep(2.0)
+            for r, p in enumerate(procs):
+                if rcs[r] is None and p.poll() is None:
+                    p.kill()                               # exactly the PIDs started above
+                    rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() if c is None else c for p, c in zip(procs, rcs)]
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        sys.exit(1)
+
+
+def host_threads():
+    """CPUs this process may run on (the affinity mask, cut by a cgroup v2 CPU quota if one is set)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +120,7 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-seconds (threads x wall) for the CPU baseline")
     ap.add_argument("--cpu-frames", type=int, default=2048)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="second CPU figure next to 1 thread and all cores")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this GPU")
@@ -76,10 +129,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus, sys.argv[1:])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    import torch
     dev_index = local_rank if args.force_device is None else args.force_device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -155,6 +210,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     tot_err, tot_bits = int(counters[0].item()), int(counters[1].item())
+    # per-frame error counts of the whole job in global frame order (outside the timed region): the digest must not
+    # depend on how many ranks shared the frames out
+    ferr = out["errors"].to(torch.int32).to(cdev).contiguous()
+    if world > 1:
+        parts = [torch.empty_like(ferr) for _ in range(world)]
+        dist.all_gather(parts, ferr)
+        ferr = torch.cat(parts)
+    ferr = ferr.cpu().numpy()
 
     if rank == 0:
         sym_per_step = F * cfg.N_symb * world
@@ -177,6 +240,8 @@ def main():
                                    "6-tap channel 20 dB, frames of 14 symbols",
                        "frames_per_gpu": F, "symbols_per_step": sym_per_step, "sharding": f"frames x{world}"},
             "ber": tot_err / max(tot_bits, 1),
+            "frame_errors": {"frames": int(ferr.size), "sum": int(ferr.sum()),
+                             "sha1": __import__("hashlib").sha1(ferr.astype("<i4").tobytes()).hexdigest()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ofdm_rx_chain_task5 = " + " + ".join(knames) +
@@ -186,15 +251,17 @@ def main():
         }
         # HBM bytes per step from the committed PMC passes (cannot be collected from inside this process): only
         # quoted when this run is the workload those passes profiled
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "traffic.json")
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        rounds = sorted(d for d in os.listdir(pdir) if os.path.exists(os.path.join(pdir, d, "traffic.json")))
+        tpath = os.path.join(pdir, rounds[-1], "traffic.json") if rounds else ""
         tj = None
-        if os.path.exists(tpath) and args.precision == "fp32":
+        if tpath and args.precision == "fp32":
             with open(tpath) as f:
                 tj = json.load(f)
         if tj is not None and tj.get("frames", 8192) == F:
             res["roofline"]["traffic"] = tj["chain_bytes_per_step"]
             res["roofline"]["algorithmic_bytes"] = b_sym * F * cfg.N_symb
-            res["roofline"]["traffic_source"] = ("profiles/round1/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+            res["roofline"]["traffic_source"] = (os.path.relpath(tpath, os.path.dirname(pdir)) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                  "passes of this command (tools/pmc.sh), FETCH_SIZE doubled for gfx950")
         # dominant kernel alone: symbols 2..S of every frame + stash + bits out + reference bits in
         nd_, np_ = len(cfg.dataCarriers), len(cfg.pilotCarriers)
@@ -205,16 +272,23 @@ def main():
                                     "unit": "GB/s", "frac": b_dom / (float(kms[2]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu:
             ncpu = min(args.cpu_frames, F)
-            nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            nall = max(1, min(host_threads(), ncpu // 4))
+            nthr = max(1, min(args.cpu_threads, nall))
             rx_host = np.ascontiguousarray(rx.t()[:ncpu].contiguous().cpu().numpy().astype(np.complex128))
-            cb = cpu_baseline(cfg, rx_host, data["pilots"], data["bits"], args.cpu_seconds, nthr)
+            cb = cpu_baseline(cfg, rx_host, data["pilots"], data["bits"], args.cpu_seconds, nall)
+            cb16 = cb if nthr == nall else cpu_baseline(cfg, rx_host, data["pilots"], data["bits"],
+                                                        args.cpu_seconds / 2, nthr)
             gpu_errs = out["errors"][:ncpu].cpu().numpy().astype(np.int64)
             res["cpu_baseline"] = {
-                "value": cb["value"], "unit": "OFDM symbols/s", "cores": nthr, "kind": "port",
+                "value": cb["value"], "unit": "OFDM symbols/s", "cores": nall, "kind": "port",
                 "single_thread_value": cb["single"],
+                "threads": {"1": cb["single"], str(nthr): cb16["value"], str(nall): cb["value"]},
+                "host_cpu_count": os.cpu_count(), "usable_cpus": host_threads(),
                 "sample": f"first {ncpu} of the {F} benchmark frames ({ncpu * cfg.N_symb} symbols) x {cb['passes']} passes, "
-                          f"{cb['wall']:.2f} s wall on {nthr} OpenMP threads; C restatement of the .m reference "
-                          f"(oracle/c/ofdm_oracle.c, float64), not MATLAB; host has {os.cpu_count()} cores"}
+                          f"{cb['wall']:.2f} s wall on {nall} OpenMP threads = every CPU this process may use "
+                          f"(os.cpu_count() = {os.cpu_count()}, affinity / cgroup quota = {host_threads()}); also 1 thread "
+                          f"(64 frames) and {nthr} threads; C restatement of the .m reference "
+                          f"(oracle/c/ofdm_oracle.c, float64), not MATLAB"}
             res["ber_match"] = {"frames": int(ncpu), "gpu_errors": int(gpu_errs.sum()),
                                 "oracle_errors": int(cb["errors"].sum()),
                                 "max_abs_diff_per_frame": int(np.max(np.abs(gpu_errs - cb["errors"])))}

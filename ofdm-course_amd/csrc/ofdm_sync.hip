@@ -219,11 +219,14 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
   int64_t rank_base = 0;       // kept elements before this chunk
   double sum = 0.0;
   int64_t cnt = 0;
-  for (int64_t base = 0; base < pv.M; base += FS_THREADS) {
+  // length of `taus`: T5/fine_sync.m:8 allocates numel(pilotValues) entries (the loop leaves the last one 0);
+  // T4/fine_sync.m:8 allocates Np and lets the loop of :25-30 grow it to numel-1 entries -- no trailing 0
+  const int64_t L = (variant == 1 && pv.M - 1 >= pv.np) ? pv.M - 1 : pv.M;
+  for (int64_t base = 0; base < L; base += FS_THREADS) {
     const int64_t i = base + tid;
     bool keep = false;
     double ti = 0.0;
-    if (i >= 1 && i < pv.M) {
+    if (i >= 1 && i < L) {
       ti = pv.tau_at(i, inv);
       const double d = ti - pv.tau_at(i - 1, inv);
       keep = fabs(d) < 1e-3;                                     // fine_sync.m:18

@@ -371,7 +371,8 @@ def remove_IFO(rx_signal, Nfft):
 
 
 def fine_sync(rx_signal, pilotCarriers, pilotValues, time_desync, freq_desync, variant="T5"):
-    """T5/fine_sync.m:1-45 (variant='T4': T4/fine_sync.m also masks diff~=0, :33).
+    """T5/fine_sync.m:1-45 (variant='T4': T4/fine_sync.m also masks diff~=0, :33, and its `taus` has no trailing
+    zero: `zeros(1, Np)` on :8 is grown by the loop of :25-30 to numel-1 entries, where T5's :8 allocates numel).
 
     Documented deviations: nn = 0:size(rx,1)-1 instead of the hard-coded
     0:1024-1 (:24; identical when Nfft=1024); angle(0) := 0 (signed zeros).
@@ -388,6 +389,8 @@ def fine_sync(rx_signal, pilotCarriers, pilotValues, time_desync, freq_desync, v
     q = txf * np.conj(rxf)                                          # :11-12
     taus = np.zeros(txf.size)
     taus[:-1] = _angle0(q[1:] * np.conj(q[:-1])) / (2 * np.pi * deltak)   # :14
+    if variant == "T4" and txf.size - 1 >= pc.size:
+        taus = taus[:-1]                                            # T4/fine_sync.m:8 + :25-30
     diffs = np.diff(taus)
     if variant == "T4":
         mask = np.concatenate([[False], (np.abs(diffs) < 1e-3) & (diffs != 0)])

@@ -60,3 +60,18 @@ def test_two_rank_sweep_matches_single_process():
             want_n[s, 0] += n
     for _, e, n in res:                 # every rank holds the global totals, bit-identical
         assert np.array_equal(e, want_e) and np.array_equal(n, want_n)
+
+
+def test_bench_parent_reports_a_failed_rank_instead_of_hanging():
+    """bench.py's own launcher (`python bench.py --gpus 2`): on this GPU-less host both ranks fail at
+    torch.cuda.set_device; the parent must relay that as a non-zero exit code quickly, without any GPU call itself."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--frames", "8", "--backend", "gloo", "--no-cpu"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and r.stdout.strip().startswith("{")
+    else:
+        assert r.returncode == 1 and "ranks failed" in r.stderr, (r.returncode, r.stderr[-500:])

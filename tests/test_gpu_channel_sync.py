@@ -183,3 +183,20 @@ def test_t4_chain_sync_to_bits(ofdm, oracle):
     err = bits != sg["bits"]
     assert not err[per_sym:].any()                                       # symbols 2..S error free
     assert ofdm.BER_func(sg["bits"], bits) < 0.2                          # the driver's gate (T4:367)
+
+
+@pytest.mark.parametrize("variant", ["T4", "T5"])
+def test_fine_sync_small_residual_delay_distinguishes_the_variants(ofdm, oracle, variant):
+    """tau = 2e-4 (inside the 1e-3 mask): T5/fine_sync.m averages its trailing taus(end) = 0 into tau, T4/fine_sync.m's
+    grown array has no such entry (:8, :25-30).  Kernel == oracle for both, and the two differ."""
+    rng = np.random.default_rng(11)
+    nfft, ns = 256, 3
+    pc = np.arange(1, 101, 6)
+    pv = np.repeat(np.where(np.arange(len(pc)) % 2 == 0, 1.5, -1.5).astype(complex)[:, None], ns, axis=1)
+    X = crandn(rng, nfft, ns)
+    X[pc - 1, :] = pv
+    X = X * np.exp(-2j * np.pi * 2e-4 * np.arange(nfft))[:, None] + 1e-6 * crandn(rng, nfft, ns)
+    _, tau, _ = ofdm.fine_sync(X, pc, pv, 1, 0, variant=variant, return_estimates=True)
+    tau_w = oracle.fine_sync(X, pc, pv, 1, 0, variant=variant)[1]
+    other = oracle.fine_sync(X, pc, pv, 1, 0, variant="T5" if variant == "T4" else "T4")[1]
+    assert abs(tau - tau_w) < 1e-12 and abs(tau - other) > 1e-6

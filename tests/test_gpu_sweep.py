@@ -39,3 +39,28 @@ def test_two_rank_sweep_equals_single_process(tmp_path, config, estimator):
     assert one["errors"] == two["errors"] and one["bits"] == two["bits"]
     assert one["BER"][0] > one["BER"][-1] >= 0.0
     assert sum(one["bits"]) > 0
+
+
+def _bench(*argv):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as a bare command (no torch.distributed.run): the parent spawns the two ranks itself
+    (here both on GPU 0 over gloo).  Weak scaling with global frame ids: 2 ranks x 512 frames decode exactly the frames
+    of 1 rank x 1024, so the per-frame error digest is the same."""
+    two = _bench("--gpus", "2", "--backend", "gloo", "--force-device", "0", "--steps", "5", "--warmup", "2",
+                 "--frames", "512", "--no-cpu")
+    one = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--frames", "1024", "--no-cpu")
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["steps"] == 5
+    assert two["frame_errors"] == one["frame_errors"] and one["frame_errors"]["frames"] == 1024
+    assert two["config"]["symbols_per_step"] == one["config"]["symbols_per_step"] == 1024 * 14
+    assert two["scaling"] == "weak" and two["value"] > 0 and "roofline" in two

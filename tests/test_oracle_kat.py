@@ -161,3 +161,42 @@ def test_papr_kat():
     assert o.calculate_window_PAPR(y, 401).size == 0
     xs, c = o.calculateCCDF([3.0, 1.0, 2.0, 2.0, np.nan])
     assert np.array_equal(xs, [1, 1, 2, 3]) and np.array_equal(c, [1, 0.75, 0.25, 0])
+
+
+def _fine_sync_tau_literal(rx_signal, pilotCarriers, pilotValues, t4):
+    """T4/fine_sync.m:4-35 / T5/fine_sync.m:4-20 statement by statement with MATLAB's growing-array semantics (the
+    check for oracle.fine_sync's vectorised form): returns tau."""
+    txv = np.asarray(pilotValues).ravel(order="F")
+    rxv = np.asarray(rx_signal)[np.asarray(pilotCarriers, int) - 1, :].ravel(order="F")
+    deltak = pilotCarriers[1] - pilotCarriers[0]
+    taus = [0.0] * (np.asarray(pilotValues).shape[0] if t4 else txv.size)          # :8
+    for i in range(2, txv.size + 1):                                                # :25 / :10
+        q_k_1 = txv[i - 2] * np.conj(rxv[i - 2])
+        q_k = txv[i - 1] * np.conj(rxv[i - 1])
+        v = float(np.angle(q_k * np.conj(q_k_1)) / (2 * np.pi * deltak))
+        if i - 1 > len(taus):
+            taus.append(v)                                                          # MATLAB grows the row
+        else:
+            taus[i - 2] = v
+    taus = np.array(taus)
+    diffs = np.diff(taus)
+    mask = np.concatenate([[False], (np.abs(diffs) < 1e-3) & (diffs != 0) if t4 else np.abs(diffs) < 1e-3])
+    return float(np.mean(taus[mask][len(pilotCarriers):]))
+
+
+def test_fine_sync_t4_has_no_trailing_zero():
+    """Residual delay of 0.2 samples (tau = 2e-4 < the 1e-3 mask): T5's trailing taus(end) = 0 is averaged into tau,
+    T4's grown array has no such entry."""
+    rng = np.random.default_rng(11)
+    nfft, ns = 256, 3
+    pc = np.arange(1, 101, 6)
+    pv = np.repeat(np.where(np.arange(len(pc)) % 2 == 0, 1.5, -1.5).astype(complex)[:, None], ns, axis=1)
+    X = (rng.standard_normal((nfft, ns)) + 1j * rng.standard_normal((nfft, ns)))
+    X[pc - 1, :] = pv
+    X *= np.exp(-2j * np.pi * 2e-4 * np.arange(nfft))[:, None]
+    X += 1e-6 * (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape))
+    t4 = o.fine_sync(X, pc, pv, 1, 0, variant="T4")[1]
+    t5 = o.fine_sync(X, pc, pv, 1, 0, variant="T5")[1]
+    assert abs(t4 - _fine_sync_tau_literal(X, pc, pv, True)) < 1e-15
+    assert abs(t5 - _fine_sync_tau_literal(X, pc, pv, False)) < 1e-15
+    assert abs(t4 - 2e-4) < 2e-7 and 1e-6 < abs(t4 - t5) < 2e-5          # the spurious 0 pulls T5 down
