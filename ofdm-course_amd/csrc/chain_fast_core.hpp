@@ -486,6 +486,11 @@ int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t*
 template <typename T>
 int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames);
 
+// ofdm_chain_wave.hip: the symbol stage with one wavefront per frame (Nfft 2048, fp32, N_carrier <= 512)
+bool chain_wave_supported(const FastPlanView& pv);
+int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, const void* rx, int64_t n_frames, void* bits,
+                           const void* ref, void* errs, void* h_out, void* idx_out);
+
 // ofdm_chain_pilot.hip: symbol-1 transform + OMP of every frame in one launch (comb pilots, taps <= OMP_RT)
 template <typename T>
 int pilot_omp_run(const FastParams<T>& P, int nfft, bool prune2, int lg_up, const void* rx, int64_t n_frames);

@@ -610,6 +610,13 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
   }
   if (pv.ev && !fused) OFDM_HIP(hipEventRecord(pv.ev[2], st));
   // kernel 3
+  if constexpr (std::is_same<T, float>::value && NW == 4 && PRUNE2) {
+    if (chain_wave_supported(pv)) {                  // one wavefront per frame, no workgroup barrier (ofdm_chain_wave.hip)
+      OFDM_TRY(chain_wave_symbols_run(pv, P, rx, n_frames, bits, ref, errs, h_out, idx_out));
+      if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
+      return OFDM_OK;
+    }
+  }
   {
     constexpr int N = 512 * NW;
     const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS) +

@@ -1,0 +1,21 @@
+# usage: tools/clock_probe.sh <outdir> ; effective shader clock (GRBM_GUI_ACTIVE / 8 / duration) of the symbol kernel with and
+# without its sample stream (OFDM_WAVE_ABL=1 = diagnostic build that issues no sample loads in the symbol loop)
+out=$1; mkdir -p $out; root=$PWD; cd /tmp && export TMPDIR=/tmp && cd $root
+for v in normal abl; do
+  if [ $v = abl ]; then export OFDM_WAVE_ABL=1; else unset OFDM_WAVE_ABL; fi
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/$v -- python bench.py --no-cpu --steps 200 --warmup 20 > $out/$v.log 2>&1 || echo "pass $v failed"
+done
+python - <<PY
+import csv, glob
+for v in ("normal", "abl"):
+    cc = glob.glob("$out/%s/*/*counter_collection.csv" % v)[0]; kt = glob.glob("$out/%s/*/*kernel_trace.csv" % v)[0]
+    dur = {}
+    for r in csv.DictReader(open(kt)):
+        if "rx_symbols" in r["Kernel_Name"]: dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    ga = {}
+    for r in csv.DictReader(open(cc)):
+        if "rx_symbols" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE": ga[r["Dispatch_Id"]] = float(r["Counter_Value"])
+    ids = sorted(set(dur) & set(ga), key=int)[20:]
+    clk = [ga[i] / 8 / dur[i] / 1e9 for i in ids]
+    print(v, "launches", len(ids), "mean duration us %.1f" % (1e6 * sum(dur[i] for i in ids) / len(ids)), "effective clock GHz %.3f" % (sum(clk) / len(clk)))
+PY

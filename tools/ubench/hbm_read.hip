@@ -55,6 +55,36 @@ __global__ __launch_bounds__(256) void read_flat(const float4* __restrict__ x, f
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+// one WAVEFRONT per frame (the shape of rx_symbols_wave_kernel): lane l reads x[l + 64 j], j < 32, of every 2048-sample
+// symbol with 8-byte nontemporal loads (W8 = true) or 16-byte ones (lane l reads samples 2l, 2l+1 of every 128)
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool W8>
+__global__ __launch_bounds__(512) void read_frames_wave(const float* __restrict__ x, float* out, long n_frames, int n_symb) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long)gridDim.x * (blockDim.x >> 6);
+  float acc = 0;
+  for (long f = wave; f < n_frames; f += n_waves) {
+    const float* p = x + f * (long)(2304 * 2) * n_symb;
+    for (int s = 0; s < n_symb; ++s) {
+      const float* q = p + (long)s * 4608 + 512;
+      if constexpr (W8) {
+        v2f v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load((const v2f*)q + lane + 64 * j);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc += v[j].x + v[j].y;
+      } else {
+        v4f v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load((const v4f*)q + lane + 64 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
 int main() {
   const long n_frames = 8192;
   const int n_symb = 14, sym_f4 = 2048 * 8 / 16, guard_f4 = 256 * 8 / 16;
@@ -89,6 +119,21 @@ int main() {
     float ms; hipEventElapsedTime(&ms, a, b);
     const double rd = (double)n_frames * n_symb * sym_f4 * 16;
     printf("frames nt wg/cu=%d skip_guard=1: %.1f us/launch, %.0f GB/s\n", wg_per_cu, ms * 100, rd / (ms / 10 * 1e-3) / 1e9);
+  }
+  for (int w8 : {1, 0}) {
+    for (int waves_per_cu : {8, 12, 16}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(a);
+        for (int it = 0; it < 10; ++it) {
+          if (w8) hipLaunchKernelGGL(read_frames_wave<true>, dim3(256 * waves_per_cu / 4), dim3(256), 0, 0, (const float*)x, out, n_frames, n_symb);
+          else hipLaunchKernelGGL(read_frames_wave<false>, dim3(256 * waves_per_cu / 4), dim3(256), 0, 0, (const float*)x, out, n_frames, n_symb);
+        }
+        hipEventRecord(b); hipEventSynchronize(b);
+      }
+      float ms; hipEventElapsedTime(&ms, a, b);
+      const double rd = (double)n_frames * n_symb * sym_f4 * 16;
+      printf("wave-per-frame nt %d-byte loads, %d waves/cu: %.1f us/launch, %.0f GB/s\n", w8 ? 8 : 16, waves_per_cu, ms * 100, rd / (ms / 10 * 1e-3) / 1e9);
+    }
   }
   for (int wg_per_cu : {4, 8, 16}) {
     for (int rep = 0; rep < 2; ++rep) {
