@@ -22,6 +22,7 @@
 // Global loads are 16 bytes per lane (NW = 4); DIF and second-pass twiddles live in registers, third-pass
 // twiddles in an LDS table.
 #include "chain_fast_core.hpp"
+#include "omp_wave_core.hpp"
 
 namespace ofdm {
 
@@ -95,18 +96,20 @@ struct OmpLayout {          // byte offsets into dynamic LDS
 template <typename T>
 static OmpLayout omp_layout(int np, int k_atoms, int taps, int fft_elems = 0) {
   OmpLayout o;
-  // per frame: R (taps*taps), z, x, l (taps each) complex T; picks (taps ints); ctl (n, stop) + rho (double)
-  o.state_bytes = (unsigned)((sizeof(cx<T>) * ((size_t)taps * taps + 3 * taps) + sizeof(int) * (taps + 8) + 15) & ~15u);
+  const bool wave = taps > OMP_RT;            // more than OMP_RT taps: one frame per wavefront (omp_wave_core.hpp)
+  // per frame: up to OMP_RT taps nothing (registers); beyond, R = L^-1 [taps][odd stride] complex T
+  o.state_bytes = wave ? (unsigned)((sizeof(cx<T>) * (size_t)taps * omp_wave_rs(taps) + 15) & ~15u) : 16u;
+  const size_t gram_elems = wave ? 2 * (size_t)k_atoms : (size_t)k_atoms;      // two-sided table for the wave form
   const size_t per_frame = sizeof(cx<T>) * (np + 1) + sizeof(cx<T>) * k_atoms + o.state_bytes;
-  int fpw = 4;                // 16 frames per workgroup: 2 workgroups per CU keep 8 wavefronts in flight
-  if (const char* e = getenv("OFDM_OMP_FPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) fpw = v; }
-  while (fpw > 1 && 4 * fpw * per_frame + sizeof(cx<T>) * k_atoms > 96 * 1024) fpw >>= 1;
+  int fpw = wave ? 1 : 4;     // 16 frames per workgroup: 2 workgroups per CU keep 8 wavefronts in flight
+  if (const char* e = getenv("OFDM_OMP_FPW")) { const int v = atoi(e); if (!wave && (v == 1 || v == 2 || v == 4 || v == 8)) fpw = v; }
+  while (fpw > 1 && 4 * fpw * per_frame + sizeof(cx<T>) * gram_elems > 96 * 1024) fpw >>= 1;
   o.fpw = fpw;
   const int fb = 4 * fpw;
   unsigned b = 0;
   o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * fb * (np + 1) + 15) & ~15u);   // rows padded by one element
   o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * fb * k_atoms + 15) & ~15u);
-  o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * k_atoms + 15) & ~15u);
+  o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * gram_elems + 15) & ~15u);
   // the transform scratch of the c0 stage is dead before the per-frame OMP state is first written: same bytes
   const unsigned fft_bytes = (unsigned)((sizeof(cx<T>) * (size_t)fft_elems + 15) & ~15u);
   o.off_state = b; o.off_fft = b;
@@ -134,7 +137,15 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     const int f = i / np, p = i - f * np;
     Yl[f * YS + p] = (f0 + f < n_frames) ? P.ypil[(f0 + f) * np + p] : mk<T>(0, 0);
   }
-  for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
+  if (taps > OMP_RT) {                          // two-sided: gl[K + d] = a_k^H a_{k+d}, d in (-K, K)
+    for (int i = tid; i < 2 * K; i += 256) {
+      const int d = i - K;
+      const c64 gq = P.gram[d >= 0 ? d : (d > -K ? -d : 0)];
+      gl[i] = mk<T>((T)gq.x, (T)(d >= 0 ? gq.y : -gq.y));
+    }
+  } else {
+    for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
+  }
   __syncthreads();
   // ---- c0 = S^H Y
   if constexpr (CM > 0) {
@@ -236,137 +247,17 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
   const int fi = wave * FPW + grp;               // frame slot inside the workgroup
   const int64_t f = f0 + fi;
   const bool live = f < n_frames;
-  unsigned char* sb = smem + lay.off_state + (size_t)fi * lay.state_bytes;
-  cx<T>* Lm = (cx<T>*)sb;                        // [taps][taps] R = L^-1 (lower triangular), generic path only
-  cx<T>* zv = Lm + (size_t)taps * taps;          // L z = b
-  cx<T>* xv = zv + taps;                         // L^H x = z
-  cx<T>* lv = xv + taps;                         // new Cholesky row (scratch)
-  int* picks = (int*)(lv + taps);
-  int* ctl = picks + ((taps + 1) & ~1);          // [0] picks made, [1] stopped, [2..3] residual energy (double)
   const cx<T>* yf = Yl + fi * YS;
   const cx<T>* cf = c0 + fi * K;
   double ynorm = 0;
   for (int p = sl; p < np; p += LPF) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
   for (int off = LPF >> 1; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
-  if (sl == 0) { ctl[0] = 0; ctl[1] = live ? 0 : 1; ((double*)(ctl + 2))[0] = ynorm; }
-  wave_sync();
-  const T g0 = gl[0].x;
   if (taps <= OMP_RT) {
     omp_frame_reg<T>(P, cf, gl, K, taps, LPF, sl, live, ynorm, f);
-    return;
-  }
-  // ---- generic path (more than 8 taps): per-frame state in LDS, every step spread over the group's lanes.
-  // The LS refit keeps R = L^-1 (inverse of the Cholesky factor of the picked atoms' Gram) instead of L, which turns
-  // the two triangular solves into O(n) work per lane: with row l = G(n, 0..n-1) R^H of the new Cholesky row
-  //   lambda^2 = G(n,n) - |l|^2,   z_n = (c0(kp) - l z) / lambda,   R(n, j) = -(1/lambda) sum_{k>=j} l_k R(k, j),
-  //   x_j += conj(R(n, j)) z_n  (j < n),   x_n = z_n / lambda                      (x = L^-H z = R^H z)
-  auto group_sum = [&](T v) { for (int off = LPF >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64); return v; };
-  for (int it = 0; it < taps; ++it) {
-    const int n = ctl[0];
-    const bool active = ctl[1] == 0;
-    // residual correlation c = c0 - G(:,index) x and its first arg-max (OMP_estimate.m:7,:14)
-    float bs = -1.0f;
-    int bi = 0x7fffffff;
-    if (active) {
-      // eight atoms of the lane at a time: the picked index and its coefficient (group-uniform LDS reads) are fetched
-      // once per term and reused for the eight partial sums -- the stage is bound by its LDS reads
-      for (int kb = sl; kb < K; kb += 8 * LPF) {
-        cx<T> c[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = kb + u * LPF < K ? cf[kb + u * LPF] : mk<T>(0, 0);
-        for (int qq = 0; qq < n; ++qq) {
-          const int pq = picks[qq];
-          const cx<T> xq = xv[qq];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int d = pq - (kb + u * LPF);
-            const int ad = d >= 0 ? d : -d;
-            const cx<T> gv = gl[ad < K ? ad : 0];
-            c[u] = c[u] - (d >= 0 ? gv : conj(gv)) * xq;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = kb + u * LPF;
-          if (k < K) {
-            const float sc = (float)((double)c[u].x * c[u].x + (double)c[u].y * c[u].y);
-            if (sc > bs) { bs = sc; bi = k; }      // ascending k inside a lane: strict > keeps the first
-          }
-        }
-      }
-    }
-    const float gmax = group_max_f(bs, LPF, lane);
-    bi = group_min_i(bs == gmax ? bi : 0x7fffffff, LPF, lane);
-    const int kp = bi < K ? bi : 0;                // all-NaN scores: MATLAB max returns index 1
-    if (active) {                                  // group-uniform
-      int dup = -1;
-      for (int qq = 0; qq < n; ++qq) if (picks[qq] == kp) dup = qq;
-      if (dup >= 0) {
-        // pinv with a repeated column splits the coefficient equally; residual unchanged -> break
-        wave_sync();
-        if (sl == 0) {
-          const cx<T> half = xv[dup] * (T)0.5;
-          xv[dup] = half; xv[n] = half; picks[n] = kp;
-          ctl[0] = n + 1; ctl[1] = 1;
-        }
-      } else {
-        // l_j = sum_{k<=j} G(n,k) conj(R(j,k)),  G(n,k) = a_n^H a_k = gram[idx_k - idx_n]
-        T nrm = T(0);
-        cx<T> lz = mk<T>(0, 0);
-        for (int j = sl; j < n; j += LPF) {
-          cx<T> l = mk<T>(0, 0);
-          for (int k = 0; k <= j; ++k) {
-            const int d = picks[k] - kp;
-            const cx<T> g = d >= 0 ? gl[d] : conj(gl[-d]);
-            l = l + mulc(g, Lm[j * taps + k]);
-          }
-          lv[j] = l;
-          nrm += norm2(l);
-          lz = lz + l * zv[j];
-        }
-        nrm = group_sum(nrm);
-        lz.x = group_sum(lz.x);
-        lz.y = group_sum(lz.y);
-        const T inv = T(1) / sqrt(g0 - nrm);
-        const cx<T> zn = (cf[kp] - lz) * inv;      // b_n = a_n^H y = c0[kp]
-        wave_sync();                               // lv visible to the whole group
-        for (int j = sl; j < n; j += LPF) {
-          cx<T> r = mk<T>(0, 0);
-          for (int k = j; k < n; ++k) r = r + lv[k] * Lm[k * taps + j];
-          r = r * (-inv);
-          Lm[n * taps + j] = r;
-          xv[j] = xv[j] + conj(r) * zn;
-        }
-        if (sl == 0) {
-          Lm[n * taps + n] = mk<T>(inv, 0);
-          xv[n] = zn * inv;
-          zv[n] = zn;
-          picks[n] = kp;
-          // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)
-          const double rho_prev = ((double*)(ctl + 2))[0];
-          const double num = (double)zn.x * zn.x + (double)zn.y * zn.y;
-          ((double*)(ctl + 2))[0] = rho_prev - num;
-          ctl[0] = n + 1;
-          ctl[1] = (it >= 1 && (!(num > 0.0) || num < 1e-4 * rho_prev)) ? 1 : 0;
-        }
-      }
-    }
-    wave_sync();
-  }
-  // est_fade_chan(index(i1)) = x(i1): a later duplicate overwrites an earlier one (:31-33)
-  const int n = ctl[0];
-  if (live) {
-    for (int t = sl; t < taps; t += LPF) {
-      int idx = -1;
-      c64 xo{0, 0};
-      if (t < n) {
-        idx = picks[t];
-        xo = c64{(double)xv[t].x, (double)xv[t].y};
-        for (int q2 = t + 1; q2 < n; ++q2) if (picks[q2] == idx) xo = c64{0, 0};
-      }
-      P.tap_idx[f * taps + t] = idx;
-      P.tap_x[f * taps + t] = xo;
-    }
+  } else {
+    // one frame per wavefront (lay.fpw == 1): picks / coefficients in lanes, R = L^-1 in LDS (omp_wave_core.hpp)
+    cx<T>* Rm = (cx<T>*)(smem + lay.off_state + (size_t)fi * lay.state_bytes);
+    omp_frame_wave<T>(P, cf, gl, Rm, K, taps, live, ynorm, f);
   }
 }
 

@@ -122,17 +122,17 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
     }
     __syncthreads();
     const cx<T>* xf = xk + f * P.n_symb * (int64_t)x_stride;
-    // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by
-    // the bytes it keeps in flight
-    for (int s0 = 0; s0 < P.n_symb; s0 += 2)
-      for (int k0 = gid; k0 < nc; k0 += 8 * 256) {
-        cx<T> xv[2][8];
-        int dv[8];
+    // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by the bytes it
+    // keeps in flight (a register double buffer of the next step was measured: 170 VGPRs, half the wavefronts, slower)
+    for (int k0 = gid; k0 < nc; k0 += 8 * 256) {
+      int dv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = k0 + 256 * u;
-          dv[u] = k < nc ? (int)P.drole[k] : -1;
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 256 * u;
+        dv[u] = k < nc ? (int)P.drole[k] : -1;
+      }
+      for (int s0 = 0; s0 < P.n_symb; s0 += 2) {
+        cx<T> xv[2][8];
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
               codes[(s0 + v) * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xs * geq[k0 + 256 * u]);
             }
       }
+    }
     __syncthreads();
     const unsigned int err = pack_frame<2 * BA>(codes, n_codes, bps, P.frame_words,
                                                 bits_out ? bits_out + f * P.frame_words : nullptr,
@@ -170,10 +171,13 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
 // pruned when only bins < 2048 are kept).  Persistent 512-thread workgroups; the kept rows are collected in LDS and
 // written out contiguously.
 template <typename T, bool PRUNE2>
-__global__ __launch_bounds__(512) void demod_keep8192_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ x,
+__global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ x,
                                                              const cx<T>* __restrict__ tw4096, const cx<T>* __restrict__ tw8192,
-                                                             int64_t n_symb, int t_guard, int n_keep) {
+                                                             int64_t n_symb, int t_guard, int n_keep,
+                                                             cx<T>* __restrict__ ypil /* or null */, const int32_t* __restrict__ pc0,
+                                                             const cx<T>* __restrict__ pilots, int np, int n_symb_frame) {
   constexpr int NW = 8;
+  constexpr int psh = 4;                                       // staging pad: one element every 16
   constexpr int NOUT = PRUNE2 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cx<T>* lwv = (cx<T>*)smem;                                   // [NW][WAVE_LDS_ELEMS]; also the output staging
@@ -220,26 +224,40 @@ __global__ __launch_bounds__(512) void demod_keep8192_kernel(const cx<T>* __rest
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) oo[t] = b[t];
     __syncthreads();                                           // every wavefront is done with its private region
-    // bin k' = NW (lane + 64 t) + wave of each half  ->  rows 2k' (even) and 2k'+1 (odd); staged in 4608-row pieces
-    for (int base = 0; base < n_keep; base += NW * WAVE_LDS_ELEMS) {
+    // bin k' = NW (lane + 64 t) + wave of each half  ->  rows 2k' (even) and 2k'+1 (odd); staged in pieces of STG rows.
+    // Neighbouring lanes hold rows 16 apart: the staging index is padded by one element every 16 (row i at i + i/16), which
+    // makes the scatter conflict-free (it was 16-way: SQ_LDS_BANK_CONFLICT 40 % of the kernel's LDS cycles) and keeps the
+    // contiguous read-out at most 2-way.  Optionally the pilot LS values Y = X(pilotCarriers, 1) ./ pilotValues(:, 1) of a
+    // frame's first symbol are taken from the staged rows (Task5_part2.m:190): no separate pass over X.
+    constexpr int STG = (NW * WAVE_LDS_ELEMS) * 16 / 17;         // rows per piece
+    for (int base = 0; base < n_keep; base += STG) {
 #pragma unroll
       for (int t = 0; t < NOUT; ++t) {
         const int k = 2 * (NW * (lane + 64 * t) + wave) - base;
-        if (k >= 0 && k < NW * WAVE_LDS_ELEMS && k + base < n_keep) lwv[k] = oe[t];
-        if (k + 1 >= 0 && k + 1 < NW * WAVE_LDS_ELEMS && k + 1 + base < n_keep) lwv[k + 1] = oo[t];
+        if (k >= 0 && k < STG && k + base < n_keep) lwv[k + (k >> psh)] = oe[t];
+        if (k + 1 >= 0 && k + 1 < STG && k + 1 + base < n_keep) lwv[k + 1 + ((k + 1) >> psh)] = oo[t];
       }
       __syncthreads();
       cx<T>* dst = x + s * (int64_t)n_keep + base;
-      const int cnt = n_keep - base < NW * WAVE_LDS_ELEMS ? n_keep - base : NW * WAVE_LDS_ELEMS;
-      for (int i = gid; i < cnt; i += 512) nt_store(dst + i, lwv[i]);
-      if (base + NW * WAVE_LDS_ELEMS < n_keep) __syncthreads();
+      const int cnt = n_keep - base < STG ? n_keep - base : STG;
+      for (int i = gid; i < cnt; i += 512) nt_store(dst + i, lwv[i + (i >> psh)]);
+      const unsigned su = (unsigned)s, fr = su / (unsigned)n_symb_frame;    // symbol counts fit 32 bits (checked on the host)
+      if (ypil && su - fr * (unsigned)n_symb_frame == 0u) {
+        for (int p = gid; p < np; p += 512) {
+          const int k = pc0[p] - base;
+          if (k >= 0 && k < cnt) ypil[(size_t)fr * np + p] = cdiv(lwv[k + (k >> psh)], pilots[p]);
+        }
+      }
+      if (base + STG < n_keep) __syncthreads();
     }
   }
 }
 
 template <typename T>
-static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guard, int n_keep) {
+static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guard, int n_keep, void* ypil, const int32_t* pc0,
+                              const void* pilots, int np, int n_symb_frame) {
   const void *tw4 = nullptr, *tw8 = nullptr;
+  OFDM_ARG(n_symb < (int64_t)1 << 31, "rx_chain_task5: more than 2^31 symbols in one call");
   OFDM_TRY(get_twiddles(4096, std::is_same<T, double>::value, &tw4));
   OFDM_TRY(get_twiddles(8192, std::is_same<T, double>::value, &tw8));
   const size_t dyn = sizeof(cx<T>) * ((size_t)8 * WAVE_LDS_ELEMS + WAVE_TW_ELEMS);
@@ -247,7 +265,7 @@ static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guar
     const int per_cu = resident_blocks_per_cu((const void*)kern, 512, dyn);
     const unsigned grid = (unsigned)std::min<int64_t>(n_symb, (int64_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), dyn, ctx().stream, (const cx<T>*)y, (cx<T>*)x, (const cx<T>*)tw4,
-                       (const cx<T>*)tw8, n_symb, t_guard, n_keep);
+                       (const cx<T>*)tw8, n_symb, t_guard, n_keep, (cx<T>*)ypil, pc0, (const cx<T>*)pilots, np, n_symb_frame);
     return check_launch("demod_keep8192_kernel");
   };
   if (n_keep <= 2048) return launch(demod_keep8192_kernel<T, true>);
@@ -316,13 +334,22 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   hipStream_t st = ctx().stream;
   if (pv.fused_out) *pv.fused_out = 0;
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
-  if (pv.nfft == 8192 && !getenv("OFDM_SPLIT_GENERIC_FFT"))
-    OFDM_TRY(demod_keep8192_run<T>(rx, xk, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier));
-  else
+  if (pv.nfft == 8192 && !getenv("OFDM_SPLIT_GENERIC_FFT")) {
+    // the pilot LS values come out of the transform of each frame's first symbol (no pilot_ls pass)
+    const bool fuse = !getenv("OFDM_SPLIT_NO_PLS_FUSE");
+    OFDM_TRY(demod_keep8192_run<T>(rx, xk, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, fuse ? (void*)P.ypil : nullptr, d_pc0,
+                                   P.pilots, pv.np, pv.n_symb));
+    if (!fuse) {
+      hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
+                         n_frames);
+      OFDM_TRY(check_launch("pilot_ls_kernel"));
+    }
+  } else {
     OFDM_TRY(demod_keep_device(rx, xk, pv.nfft, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, pv.f64 != 0));
-  hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
-                     n_frames);
-  OFDM_TRY(check_launch("pilot_ls_kernel"));
+    hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
+                       n_frames);
+    OFDM_TRY(check_launch("pilot_ls_kernel"));
+  }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
   if (mmse) OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
   else OFDM_TRY(omp_batch_run<T>(P, n_frames));
