@@ -25,6 +25,8 @@ struct DemapTable {
   // coordinate (I axis: level rank l <-> code gray(l); Q axis: rank l <-> code gray(L-1-l))
   T thr_i[15];
   T thr_q[15];
+  // level guess of demap_square_lut: floor(x * inv_d + off) is the level rank up to +-1 (thresholds are uniform up to rounding)
+  T inv_d, off;
 };
 
 inline int gray_encode(int l) { return l ^ (l >> 1); }
@@ -74,6 +76,56 @@ inline void fill_demap_table(const std::vector<c64>& dict, const ConstellationIn
     }
   }
   for (int l = (info.kind == 1 ? (1 << info.bits_per_axis) - 1 : 0); l < 15; ++l) t.thr_i[l] = t.thr_q[l] = T(0);
+  t.inv_d = T(1);
+  t.off = T(0);
+  if (info.kind == 1 && info.bits_per_axis >= 2) {
+    const int L = 1 << info.bits_per_axis;
+    const double d = ((double)t.thr_i[L - 2] - (double)t.thr_i[0]) / (L - 2);
+    t.inv_d = (T)(1.0 / d);
+    t.off = (T)(1.0 - (double)t.thr_i[0] / d);          // x just above thr[0] -> 1
+  }
+}
+
+// Decision-threshold table of demap_square_lut in LDS: per axis L + 1 entries T[0] = -inf, T[l] = thr[l-1], T[L] = +inf
+// (I axis first, Q axis at DEMAP_LUT_Q); the true level rank li is the one with T[li] < x <= T[li + 1].
+constexpr int DEMAP_LUT_Q = 20, DEMAP_LUT_ELEMS = 40;
+template <typename T, int BA>
+__device__ __forceinline__ void demap_lut_fill(const DemapTable<T>& t, T* __restrict__ lut, int tid) {
+  constexpr int L = 1 << BA;
+  if (tid <= L) {
+    const T inf = T(__builtin_huge_valf());
+    T vi = tid == 0 ? -inf : inf, vq = vi;
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l)
+      if (tid == l + 1) { vi = t.thr_i[l]; vq = t.thr_q[l]; }
+    lut[tid] = vi;
+    lut[DEMAP_LUT_Q + tid] = vq;
+  }
+}
+
+// The same decision as demap_square with 9 instead of 2 (L - 1) VALU operations per axis: an arithmetic guess of the level
+// rank (exact up to +-1 because the thresholds are uniformly spaced up to rounding), then ONE comparison against each of the
+// two neighbouring thresholds -- the very thresholds demap_square counts, so ties and the last ulp resolve identically.
+template <typename T, int BA>
+__device__ __forceinline__ int demap_square_lut(const DemapTable<T>& t, const T* __restrict__ lut, cx<T> z) {
+  constexpr int L = 1 << BA;
+  int g[2];
+#pragma unroll
+  for (int ax = 0; ax < 2; ++ax) {
+    const T x = ax == 0 ? z.x : z.y;
+    const T* tb = lut + (ax == 0 ? 0 : DEMAP_LUT_Q);
+    int l0 = (int)floor(x * t.inv_d + t.off);                  // NaN -> 0
+    l0 = l0 < 0 ? 0 : (l0 > L - 1 ? L - 1 : l0);
+    const T lo = tb[l0], hi = tb[l0 + 1];
+    int l = l0 + (x > hi ? 1 : 0) - (x > lo ? 0 : 1);
+    g[ax] = l < 0 ? 0 : l;                                     // NaN: every comparison false, rank 0 like demap_square
+  }
+  int li = g[0], lq = g[1];
+  if (z.y != z.y) lq = L - 1;              // NaN: every distance is NaN and `min` returns index 1
+  const int ci = li ^ (li >> 1);
+  const int lr = (L - 1) - lq;
+  const int cq = lr ^ (lr >> 1);
+  return (ci << BA) | cq;
 }
 
 // Square QAM: the squared distance separates per axis and is unimodal along an axis, so the

@@ -99,7 +99,7 @@ static OmpLayout omp_layout(int np, int k_atoms, int taps, int fft_elems = 0) {
   const bool wave = taps > OMP_RT;            // more than OMP_RT taps: one frame per wavefront (omp_wave_core.hpp)
   // per frame: up to OMP_RT taps nothing (registers); beyond, R = L^-1 [taps][odd stride] complex T
   o.state_bytes = wave ? (unsigned)((sizeof(cx<T>) * (size_t)taps * omp_wave_rs(taps) + 15) & ~15u) : 16u;
-  const size_t gram_elems = wave ? 2 * (size_t)k_atoms : (size_t)k_atoms;      // two-sided table for the wave form
+  const size_t gram_elems = wave ? (size_t)((k_atoms + 511) & ~511) + k_atoms : (size_t)k_atoms;   // two-sided table for the wave form
   const size_t per_frame = sizeof(cx<T>) * (np + 1) + sizeof(cx<T>) * k_atoms + o.state_bytes;
   int fpw = wave ? 1 : 4;     // 16 frames per workgroup: 2 workgroups per CU keep 8 wavefronts in flight
   if (const char* e = getenv("OFDM_OMP_FPW")) { const int v = atoi(e); if (!wave && (v == 1 || v == 2 || v == 4 || v == 8)) fpw = v; }
@@ -137,9 +137,10 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     const int f = i / np, p = i - f * np;
     Yl[f * YS + p] = (f0 + f < n_frames) ? P.ypil[(f0 + f) * np + p] : mk<T>(0, 0);
   }
-  if (taps > OMP_RT) {                          // two-sided: gl[K + d] = a_k^H a_{k+d}, d in (-K, K)
-    for (int i = tid; i < 2 * K; i += 256) {
-      const int d = i - K;
+  if (taps > OMP_RT) {                          // two-sided: gl[KP + d] = a_k^H a_{k+d}, d in (-K, K)
+    const int KP = (K + 511) & ~511;
+    for (int i = tid; i < KP + K; i += 256) {
+      const int d = i - KP;
       const c64 gq = P.gram[d >= 0 ? d : (d > -K ? -d : 0)];
       gl[i] = mk<T>((T)gq.x, (T)(d >= 0 ? gq.y : -gq.y));
     }

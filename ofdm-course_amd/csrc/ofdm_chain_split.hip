@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
   __shared__ unsigned int sh_err;
   __shared__ int sh_tidx[FAST_MAXT];
   __shared__ c64 sh_tx[FAST_MAXT];
+  __shared__ T sh_lut[DEMAP_LUT_ELEMS];
   const int gid = threadIdx.x;
+  if constexpr (BA >= 2) demap_lut_fill<T, BA>(tab, sh_lut, gid);
   const int taps = P.taps, nd = P.nd, nc = P.n_carrier;
   const int bps = BA > 0 ? 2 * BA : P.bps;
   const int n_codes = nd * P.n_symb;
@@ -76,22 +78,24 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
       // is a 64-address gather (stride idx_q) and made this stage gather-bound; instead ONE lookup per tap gives
       // W^(idx_q (base + gid)) and the wavefront-uniform step W^(256 idx_q) carries it to the next carrier in double.
       for (int base = 0; base < nc; base += 8 * 256) {
-        double hr[8], hi[8];
+        // (sums and the eight-step twiddle recurrence in the data precision: exact table values at both ends of every
+        //  recurrence, 32 terms -- error ~1e-6 of |H| in fp32 mode, where H itself is delivered in fp32)
+        T hr[8], hi[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) hr[u] = hi[u] = 0;
         for (int q = 0; q < taps; ++q) {
           const int idx = sh_tidx[q];
           if (idx < 0) continue;                                       // wavefront-uniform
-          const c64 x = sh_tx[q];
+          const cx<T> x = mk<T>((T)sh_tx[q].x, (T)sh_tx[q].y);
           const cx<T> w0 = P.tw[(int)(((int64_t)idx * (base + gid)) & (nfft - 1))];
           const cx<T> st = P.tw[(int)(((int64_t)idx * 256) & (nfft - 1))];
-          double wr = (double)w0.x, wi = (double)w0.y;
-          const double sr = (double)st.x, si = (double)st.y;
+          T wr = w0.x, wi = w0.y;
+          const T sr = st.x, si = st.y;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             hr[u] += x.x * wr - x.y * wi;
             hi[u] += x.x * wi + x.y * wr;
-            const double nr = wr * sr - wi * si;
+            const T nr = wr * sr - wi * si;
             wi = wr * si + wi * sr;
             wr = nr;
           }
@@ -148,7 +152,11 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
                 const c64 r = rot[k0 + 256 * u];
                 xs = mk<T>((T)((double)xs.x * r.x - (double)xs.y * r.y), (T)((double)xs.x * r.y + (double)xs.y * r.x));
               }
-              codes[(s0 + v) * nd + dv[u]] = (uint8_t)slice_symbol<T, BA>(tab, xs * geq[k0 + 256 * u]);
+              const cx<T> ye = xs * geq[k0 + 256 * u];
+              int code;
+              if constexpr (BA >= 2) code = demap_square_lut<T, BA>(tab, sh_lut, ye);
+              else code = slice_symbol<T, BA>(tab, ye);
+              codes[(s0 + v) * nd + dv[u]] = (uint8_t)code;
             }
       }
     }

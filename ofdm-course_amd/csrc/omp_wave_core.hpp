@@ -5,7 +5,7 @@
 // per iteration, 0.38 ms per 2048 frames):
 //   * pick q, its coefficient x_q, z_q and the scratch row l_q live in LANE q (one register each); a wave-uniform q reads
 //     them with v_readlane -- no LDS round trip for anything that is indexed by the pick number;
-//   * the Gram table is stored two-sided (g2[d + K] = a_k^H a_{k+d}, negative shifts conjugated), so the residual
+//   * the Gram table is stored two-sided (g2[d + KP] = a_k^H a_{k+d}, negative shifts conjugated), so the residual
 //     correlation c = c0 - G(:, index) x costs one LDS gather + four FMAs per (atom, pick) and no sign logic;
 //   * R = L^-1 (lower triangular) sits in LDS with an ODD row stride: row j by lane j (new Cholesky row) and column j by
 //     lane j (update of R) are both conflict-free; each is one pass over k with wave-uniform k;
@@ -39,14 +39,15 @@ __device__ __forceinline__ double wave_sum(double v, int) {
 
 __host__ __device__ constexpr int omp_wave_rs(int taps) { return taps | 1; }          // odd row stride of R
 
-// cf = c0 of the frame [K], g2 = two-sided Gram table [2K] (index d + K), Rm = this wavefront's R [taps][omp_wave_rs(taps)]
+// cf = c0 of the frame [K], g2 = two-sided Gram table [KP + K] (index d + KP, KP = K rounded up to 512), Rm = this wavefront's R [taps][omp_wave_rs(taps)]
 template <typename T>
 __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<T>* __restrict__ cf,
                                                const cx<T>* __restrict__ g2, cx<T>* __restrict__ Rm, int K, int taps,
                                                bool live, double ynorm, int64_t f) {
   const int lane = threadIdx.x & 63;
   const int RS = omp_wave_rs(taps);
-  const T g0 = g2[K].x;
+  const int KP = (K + 511) & ~511;               // the table's zero shift sits at KP
+  const T g0 = g2[KP].x;
   int pk = -1;                                   // lane q: pick q (0-based atom), x_q, z_q
   cx<T> xq = mk<T>(0, 0), zq = mk<T>(0, 0);
   int n = 0;
@@ -61,15 +62,31 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
       cx<T> c[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) c[u] = kb + 64 * u < K ? cf[kb + 64 * u] : mk<T>(0, 0);
-      const cx<T>* gk = g2 + K - kb;             // g2[K + pq - k], k = kb + 64 u
-      for (int q = 0; q < ns; ++q) {
-        const int pq = __builtin_amdgcn_readlane(pk, q);
-        const cx<T> xv = lane_bcast(xq, q);
+      // g2[KP + pq - k], k = kb + 64 u: one address per pick (the pick is wave-uniform), eight reads at immediate offsets.
+      // The table is KP + K long (KP = K rounded up to 512), so the atoms past the end of the dictionary read in bounds;
+      // their scores are never looked at.
+      const cx<T>* gk = g2 + KP - kb - 448;
+      if (ns > 0) {
+        cx<T> ga[8], gb[8];
+        int pq = __builtin_amdgcn_readlane(pk, 0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          int o = pq - 64 * u;
-          if (kb + 64 * u >= K) o = 0;           // atoms past the end of the dictionary (K not a multiple of 512)
-          c[u] = c[u] - gk[o] * xv;
+        for (int u = 0; u < 8; ++u) ga[u] = gk[pq + 64 * (7 - u)];
+        for (int q = 0; q < ns; q += 2) {        // two picks per trip: the second pick's Gram values are in flight
+          const cx<T> xa = lane_bcast(xq, q);
+          const bool two = q + 1 < ns;
+          const int pn = __builtin_amdgcn_readlane(pk, two ? q + 1 : q);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gb[u] = gk[pn + 64 * (7 - u)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) c[u] = c[u] - ga[u] * xa;
+          if (two) {
+            const cx<T> xb = lane_bcast(xq, q + 1);
+            const int p2 = __builtin_amdgcn_readlane(pk, q + 2 < ns ? q + 2 : q + 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ga[u] = gk[p2 + 64 * (7 - u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = c[u] - gb[u] * xb;
+          }
         }
       }
 #pragma unroll
@@ -96,7 +113,7 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
     }
     // ---- new Cholesky row through R = L^-1:  l_j = sum_{k<=j} G(n,k) conj(R(j,k)),  G(n,k) = a_n^H a_k = g2[K + idx_k - idx_n]
     cx<T> g = mk<T>(0, 0);
-    if (lane < n) g = g2[K + pk - kp];
+    if (lane < n) g = g2[KP + pk - kp];
     cx<T> l = mk<T>(0, 0);
     const cx<T>* Rrow = Rm + lane * RS;
     for (int k = 0; k < ns; ++k) {
