@@ -186,25 +186,27 @@ struct PilotView {
   const cx<T>* tx;          // [np x n_symb]
   const int32_t* pc0;       // 0-based pilot rows
   int nfft, np;
-  int64_t M;
+  int64_t M;                // np * n_symb, < 2^31 (checked on the host)
   int64_t rx_fstride;       // elements between the frames of a batch (0 for a single frame)
-  __device__ void q(int64_t i, double& qr, double& qi) const {     // q = tx * conj(rx)
-    const int p = (int)(i % np);
-    const int64_t s = i / np;
-    const cx<T> r = rx[s * nfft + pc0[p]];
+  int compact;              // rx is already X(pilotCarriers, :) = [np x n_symb] (the batched receiver: written by its demodulator)
+  __device__ void q(unsigned i, double& qr, double& qi) const {    // q = tx * conj(rx)
+    const unsigned s = i / (unsigned)np, p = i - s * (unsigned)np;
+    const cx<T> r = compact ? rx[i] : rx[(size_t)s * nfft + pc0[p]];
     const cx<T> t = tx[i];
     qr = (double)t.x * r.x + (double)t.y * r.y;
     qi = (double)t.y * r.x - (double)t.x * r.y;
   }
-  __device__ double tau_at(int64_t i, double inv2pidk) const {     // taus(i), 0-based, i < M
-    if (i >= M - 1) return 0.0;
-    double ar, ai, br, bi;
-    q(i, ar, ai);
-    q(i + 1, br, bi);
-    // q(i+1) * conj(q(i))
-    return angle0(br * ar + bi * ai, bi * ar - br * ai) * inv2pidk;
-  }
 };
+
+// taus(i) = angle(q(i+1) conj(q(i))) / (2 pi dk)
+__device__ __forceinline__ double tau_of(double ar, double ai, double br, double bi, double inv2pidk) {
+  return angle0(br * ar + bi * ai, bi * ar - br * ai) * inv2pidk;
+}
+
+// Every thread owns FS_U CONSECUTIVE entries of `taus` per trip: their FS_U + 2 pilot products are requested together
+// (the kernel is bound by the latency of these gathers, not by arithmetic: one workgroup per frame), each product and
+// each angle is formed once, and a frame of 6700 pilots takes 7 trips instead of 27.
+constexpr int FS_U = 4;
 
 template <typename T>
 __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, double deltak, int variant,
@@ -216,30 +218,63 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
   __shared__ int64_t wn[FS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double inv = 1.0 / (2.0 * M_PI * deltak);
-  int64_t rank_base = 0;       // kept elements before this chunk
+  const unsigned M = (unsigned)pv.M;
+  int64_t rank_base = 0;       // kept elements before this trip
   double sum = 0.0;
   int64_t cnt = 0;
   // length of `taus`: T5/fine_sync.m:8 allocates numel(pilotValues) entries (the loop leaves the last one 0);
   // T4/fine_sync.m:8 allocates Np and lets the loop of :25-30 grow it to numel-1 entries -- no trailing 0
-  const int64_t L = (variant == 1 && pv.M - 1 >= pv.np) ? pv.M - 1 : pv.M;
-  for (int64_t base = 0; base < L; base += FS_THREADS) {
-    const int64_t i = base + tid;
-    bool keep = false;
-    double ti = 0.0;
-    if (i >= 1 && i < L) {
-      ti = pv.tau_at(i, inv);
-      const double d = ti - pv.tau_at(i - 1, inv);
-      keep = fabs(d) < 1e-3;                                     // fine_sync.m:18
-      if (variant == 1) keep = keep && (d != 0.0);               // T4/fine_sync.m:33
+  const unsigned L = (variant == 1 && pv.M - 1 >= pv.np) ? M - 1 : M;
+  for (unsigned base = 0; base < L; base += FS_THREADS * FS_U) {
+    const unsigned i0 = base + FS_U * tid;                       // entries i0 .. i0 + FS_U - 1
+    // products q(i0 - 1) .. q(i0 + FS_U): taus(i) needs q(i), q(i + 1); the first difference needs taus(i0 - 1)
+    double qr[FS_U + 2], qi[FS_U + 2];
+#pragma unroll
+    for (int u = 0; u < FS_U + 2; ++u) {
+      const long long i = (long long)i0 + u - 1;
+      qr[u] = qi[u] = 0.0;
+      if (i >= 0 && i < (long long)M && i0 < L) pv.q((unsigned)i, qr[u], qi[u]);
     }
-    const unsigned long long bal = __ballot(keep);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wcnt[wid] = __popcll(bal);
+    double tp = 0.0;                                             // taus(i0 - 1)
+    if (i0 >= 1 && i0 - 1 < M - 1) tp = tau_of(qr[0], qi[0], qr[1], qi[1], inv);
+    bool keep[FS_U];
+    double tv[FS_U];
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < FS_U; ++u) {
+      const unsigned i = i0 + u;
+      keep[u] = false;
+      tv[u] = 0.0;
+      if (i < L) {
+        tv[u] = i < M - 1 ? tau_of(qr[u + 1], qi[u + 1], qr[u + 2], qi[u + 2], inv) : 0.0;      // taus(M) = 0 (T5 form)
+        if (i >= 1) {
+          const double d = tv[u] - tp;
+          keep[u] = fabs(d) < 1e-3;                              // fine_sync.m:18
+          if (variant == 1) keep[u] = keep[u] && (d != 0.0);     // T4/fine_sync.m:33
+        }
+      }
+      tp = tv[u];
+      mine += keep[u] ? 1 : 0;
+    }
+    // rank among the kept entries, in entry order (thread-major, then u)
+    int before = 0, wtot = 0;
+#pragma unroll
+    for (int u = 0; u < FS_U; ++u) {
+      const unsigned long long bal = __ballot(keep[u]);
+      before += __popcll(bal & ((1ull << lane) - 1ull));
+      wtot += __popcll(bal);
+    }
+    if (lane == 0) wcnt[wid] = wtot;
     __syncthreads();
     int woff = 0, tot = 0;
     for (int w = 0; w < FS_THREADS / 64; ++w) { if (w < wid) woff += wcnt[w]; tot += wcnt[w]; }
-    const int64_t rank = rank_base + woff + before;              // 0-based rank among kept
-    if (keep && rank >= pv.np) { sum += ti; cnt += 1; }          // :20 taus_result(Np+1:end)
+    int64_t rank = rank_base + woff + before;                    // 0-based rank of this thread's first kept entry
+#pragma unroll
+    for (int u = 0; u < FS_U; ++u)
+      if (keep[u]) {
+        if (rank >= pv.np) { sum += tv[u]; cnt += 1; }           // :20 taus_result(Np+1:end)
+        rank += 1;
+      }
     rank_base += tot;
     __syncthreads();
   }
@@ -263,22 +298,34 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
   __shared__ int64_t wn[FS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double tau = out[0];
+  const unsigned M = (unsigned)pv.M;
   double sum = 0.0;
   int64_t cnt = 0;
-  for (int64_t i = tid; i < pv.M; i += FS_THREADS) {
-    double qr, qi;
-    pv.q(i, qr, qi);
-    if (time_desync) {
-      // rx' = rx * exp(+2 pi j tau k)  =>  q' = q * exp(-2 pi j tau k)   (fine_sync.m:25-27, nn_exp')
-      const int k = pv.pc0[(int)(i % pv.np)];
-      const double t = tau * (double)k;
-      double sn, cs;
-      sincospi(2.0 * (t - floor(t)), &sn, &cs);
-      const double r2 = qr * cs + qi * sn, i2 = qi * cs - qr * sn;
-      qr = r2; qi = i2;
+  for (unsigned base = 0; base < M; base += FS_THREADS * FS_U) {
+    double qr[FS_U], qi[FS_U];
+#pragma unroll
+    for (int u = 0; u < FS_U; ++u) {                              // FS_U gathers in flight per thread
+      const unsigned i = base + u * FS_THREADS + tid;
+      qr[u] = qi[u] = 0.0;
+      if (i < M) pv.q(i, qr[u], qi[u]);
     }
-    const double a = angle0(qr, qi);                             // :35
-    if (fabs(a) > 1e-3) { sum += a; cnt += 1; }                  // :37
+#pragma unroll
+    for (int u = 0; u < FS_U; ++u) {
+      const unsigned i = base + u * FS_THREADS + tid;
+      if (i < M) {
+        if (time_desync) {
+          // rx' = rx * exp(+2 pi j tau k)  =>  q' = q * exp(-2 pi j tau k)   (fine_sync.m:25-27, nn_exp')
+          const int k = pv.pc0[i % (unsigned)pv.np];
+          const double t = tau * (double)k;
+          double sn, cs;
+          sincospi(2.0 * (t - floor(t)), &sn, &cs);
+          const double r2 = qr[u] * cs + qi[u] * sn, i2 = qi[u] * cs - qr[u] * sn;
+          qr[u] = r2; qi[u] = i2;
+        }
+        const double a = angle0(qr[u], qi[u]);                   // :35
+        if (fabs(a) > 1e-3) { sum += a; cnt += 1; }              // :37
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); cnt += __shfl_down(cnt, off, 64); }
   if (lane == 0) { wsum[wid] = sum; wn[wid] = cnt; }
@@ -440,7 +487,8 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
                                                            const cx<T>* __restrict__ tw, int64_t len, int t_guard, int n_symb,
                                                            int64_t n_frames, int time_desync, int freq_desync,
                                                            const int64_t* __restrict__ tg, const double* __restrict__ fo,
-                                                           const int32_t* __restrict__ ifo) {
+                                                           const int32_t* __restrict__ ifo, int n_keep,
+                                                           cx<T>* __restrict__ xp, const int16_t* __restrict__ prole, int np) {
   constexpr int N = 512 * NW;
   constexpr int BPT = NW > 1 ? 8 / NW : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -471,6 +519,17 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[e] = t4_raw<T>(xf, (int64_t)sy * sym_len + t_guard + slot_m(e), len, sym_len, time_desync, pos);
   };
+  // phase (in turns) of the merged rotation add_CFO(-FreqOffset) . add_CFO(-IFO) at stream index i: the fractional part in
+  // double, the integer-offset part reduced exactly in integers (N is a power of two)
+  auto turns_at = [&](double c1, int32_t fi, int64_t i) -> double {
+    double t = c1 * (double)i * inv;
+    t -= floor(t);
+    if (fi > 0) {
+      t -= (double)(((int64_t)fi * i) & (N - 1)) * inv;
+      t += t < 0.0 ? 1.0 : 0.0;
+    }
+    return t;
+  };
   cx<T> v[8], nx[8];
   if ((int64_t)blockIdx.x < total) load_raw(nx, blockIdx.x);
   for (int64_t sg = blockIdx.x; sg < total; sg += gridDim.x) {
@@ -482,23 +541,40 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
     if (freq_desync) {
       const double c1 = -fo[f];
       const int32_t fi = ifo[f];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int64_t i = (int64_t)sy * sym_len + t_guard + slot_m(e);
-        if constexpr (std::is_same<T, float>::value) {
-          // throughput mode: add_CFO(-FreqOffset) and remove_IFO's rotation as ONE rotation -- the fractional part of the
-          // phase in double, the integer-offset part reduced exactly in integers (N is a power of two), sine / cosine
-          // in float; parity mode below keeps the reference's two roundings
-          double t = c1 * (double)i * inv;
-          t -= floor(t);
-          if (fi > 0) {
-            t -= (double)(((int64_t)fi * i) & (N - 1)) * inv;
-            t += t < 0.0 ? 1.0 : 0.0;
-          }
+      if constexpr (std::is_same<T, float>::value) {
+        // throughput mode: ONE rotation per sample.  The rotor of the thread's first sample comes from a sine / cosine of the
+        // exactly reduced phase; its other samples sit at fixed distances (e / NW) + 512 (e % NW), whose rotors are
+        // frame constants (wave-uniform: a handful of scalar sine / cosine pairs per symbol): rotor_e = rotor_0 * step_e.
+        // (Each sample used to pay two double multiplies, a floor, a 64-bit product and a sincospif of its own.)
+        const int64_t i0 = (int64_t)sy * sym_len + t_guard + slot_m(0);
+        auto rotor = [&](int64_t i) {
           float sn, cs;
-          sincospif(2.0f * (float)t, &sn, &cs);
-          v[e] = mk<T>(v[e].x * cs - v[e].y * sn, v[e].x * sn + v[e].y * cs);
-        } else {
+          sincospif(2.0f * (float)turns_at(c1, fi, i), &sn, &cs);
+          return mk<float>(cs, sn);
+        };
+        const cx<float> r0 = rotor(i0);
+        // distances (e / NW) + 512 (e % NW) [or 64 e for one wavefront per symbol]: powers of two base steps
+        constexpr int SA = NW > 1 ? 512 : 64, NA = NW > 1 ? NW : 8, NB = NW > 1 ? BPT : 1;
+        cx<float> pa[NA];                                         // rotor(SA a)
+        pa[0] = mk<float>(1.0f, 0.0f);
+        if (NA > 1) pa[1] = rotor(SA);
+#pragma unroll
+        for (int a = 2; a < NA; ++a) pa[a] = pa[a - 1] * pa[1];
+        cx<float> pb = r0;                                        // r0 * rotor(b)
+        const cx<float> r1 = NB > 1 ? rotor(1) : mk<float>(1.0f, 0.0f);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            const int e = NW > 1 ? b * NW + a : a;
+            v[e] = v[e] * (a == 0 ? pb : pb * pa[a]);
+          }
+          pb = pb * r1;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int64_t i = (int64_t)sy * sym_len + t_guard + slot_m(e);
           v[e] = t4_rotate<T>(v[e], c1, i, inv);
           if (fi > 0) v[e] = t4_rotate<T>(v[e], -(double)fi, i, inv);
         }
@@ -518,21 +594,32 @@ __global__ __launch_bounds__(64 * NW) void t4_demod_kernel(const cx<T>* __restri
 #pragma unroll
     for (int t = 0; t < 8; ++t) lwv[NW * (lane + 64 * t) + wave] = v[t];
     __syncthreads();
-    cx<T>* dst = X + sg * (int64_t)N;
+    // rows 1..n_keep of the column (everything downstream reads carriers 1..N_carrier only) + its pilot rows, compact
+    cx<T>* dst = X + sg * (int64_t)n_keep;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) nt_store(dst + gid + 64 * NW * e, lwv[gid + 64 * NW * e]);
+    for (int e = 0; e < 8; ++e) {
+      const int i = gid + 64 * NW * e;
+      if (i < n_keep) {
+        const cx<T> xv = lwv[i];
+        nt_store(dst + i, xv);
+        if (xp) {
+          const int pr = prole[i];
+          if (pr >= 0) xp[sg * (int64_t)np + pr] = xv;
+        }
+      }
+    }
   }
 }
 
 template <typename T, int NW>
 static int t4_demod_launch(const void* rx, void* X, const void* tw, int64_t len, int t_guard, int n_symb, int64_t F, int td, int fd,
-                           const int64_t* tg, const double* fo, const int32_t* ifo) {
+                           const int64_t* tg, const double* fo, const int32_t* ifo, int n_keep, void* xp, const void* prole, int np) {
   const size_t dyn = sizeof(cx<T>) * ((size_t)NW * WAVE_LDS_ELEMS + WAVE_TW_ELEMS);
   auto kern = t4_demod_kernel<T, NW>;
   const int per_cu = resident_blocks_per_cu((const void*)kern, 64 * NW, dyn);
   const unsigned grid = (unsigned)std::min<int64_t>(F * n_symb, (int64_t)ctx().num_cu * per_cu);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), dyn, ctx().stream, (const cx<T>*)rx, (cx<T>*)X, (const cx<T>*)tw, len, t_guard,
-                     n_symb, F, td, fd, tg, fo, ifo);
+                     n_symb, F, td, fd, tg, fo, ifo, n_keep, (cx<T>*)xp, (const int16_t*)prole, np);
   return check_launch("t4_demod_kernel");
 }
 
@@ -541,11 +628,11 @@ template <typename T>
 __global__ void t4_mean_pilots_kernel(const cx<T>* __restrict__ X, const cx<T>* __restrict__ tx, const int32_t* __restrict__ pc0,
                                       cx<T>* __restrict__ hp, int nfft, int np, int n_symb,
                                       const double* __restrict__ fine_est /* rotation not yet applied to X, or null */,
-                                      int time_desync, int freq_desync) {
+                                      int time_desync, int freq_desync, int compact /* X = X(pilotCarriers,:) [np x S] per frame */) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t f = blockIdx.y;
   if (p >= np) return;
-  const cx<T>* rx = X + f * (int64_t)nfft * n_symb;
+  const cx<T>* rx = X + f * (int64_t)(compact ? np : nfft) * n_symb;
   double rc = 1.0, rs = 0.0;
   if (fine_est) {                                                  // the rotation of fine_apply_kernel for row pc0[p]
     const double tau = fine_est[2 * f], ph = fine_est[2 * f + 1];
@@ -559,30 +646,55 @@ __global__ void t4_mean_pilots_kernel(const cx<T>* __restrict__ X, const cx<T>* 
     rs = sn * pcs + cs * psn;
   }
   double ar = 0, ai = 0;
-  for (int s = 0; s < n_symb; ++s) {
-    cx<T> xv = rx[(int64_t)s * nfft + pc0[p]];
-    if (fine_est) xv = mk<T>((T)((double)xv.x * rc - (double)xv.y * rs), (T)((double)xv.x * rs + (double)xv.y * rc));
-    const cx<T> q = cdiv(xv, tx[s * np + p]);
-    ar += (double)q.x;
-    ai += (double)q.y;
+  const int row = pc0[p];
+  for (int s0 = 0; s0 < n_symb; s0 += 10) {                       // ten strided samples requested together
+    cx<T> xs[10], ts[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int s = s0 + u < n_symb ? s0 + u : n_symb - 1;
+      xs[u] = compact ? rx[(int64_t)s * np + p] : rx[(int64_t)s * nfft + row];
+      ts[u] = tx[s * np + p];
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      if (s0 + u < n_symb) {
+        cx<T> xv = xs[u];
+        if (fine_est) xv = mk<T>((T)((double)xv.x * rc - (double)xv.y * rs), (T)((double)xv.x * rs + (double)xv.y * rc));
+        const cx<T> q = cdiv(xv, ts[u]);
+        ar += (double)q.x;
+        ai += (double)q.y;
+      }
+    }
   }
   hp[f * np + p] = mk<T>((T)(ar / (double)n_symb), (T)(ai / (double)n_symb));
 }
 
+// H(1..N_carrier) = W * Hp for T4_FT frames per workgroup: a weight is read once and used for all of them (one frame per
+// workgroup re-read the 429 KB operator from L2 for every frame: 70 us per 1024 frames); the pilot means are wave-uniform
+// reads.  double accumulation: the not-a-knot weights alternate in sign.
+constexpr int T4_FT = 8;
 template <typename T>
-__global__ void t4_apply_operator_kernel(const T* __restrict__ W, const cx<T>* __restrict__ hp, cx<T>* __restrict__ hout,
-                                         int n_out, int n_in) {
+__global__ __launch_bounds__(128) void t4_apply_operator_kernel(const T* __restrict__ W, const cx<T>* __restrict__ hp,
+                                                                cx<T>* __restrict__ hout, int n_out, int n_in, int64_t n_frames) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t f = blockIdx.y;
+  const int64_t f0 = (int64_t)blockIdx.y * T4_FT;
   if (m >= n_out) return;
-  double ar = 0, ai = 0;                                           // double: the not-a-knot weights alternate in sign
+  double ar[T4_FT], ai[T4_FT];
+#pragma unroll
+  for (int f = 0; f < T4_FT; ++f) ar[f] = ai[f] = 0.0;
   for (int j = 0; j < n_in; ++j) {
     const double w = (double)W[(size_t)j * n_out + m];
-    const cx<T> z = hp[f * n_in + j];
-    ar += w * (double)z.x;
-    ai += w * (double)z.y;
+#pragma unroll
+    for (int f = 0; f < T4_FT; ++f) {
+      const int64_t ff = f0 + f < n_frames ? f0 + f : n_frames - 1;
+      const cx<T> z = hp[ff * n_in + j];
+      ar[f] += w * (double)z.x;
+      ai[f] += w * (double)z.y;
+    }
   }
-  hout[f * n_out + m] = mk<T>((T)ar, (T)ai);
+#pragma unroll
+  for (int f = 0; f < T4_FT; ++f)
+    if (f0 + f < n_frames) hout[(f0 + f) * n_out + m] = mk<T>((T)ar[f], (T)ai[f]);
 }
 
 template <typename T>
@@ -608,6 +720,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   const size_t o_y = reserve(sizeof(cx<T>) * (size_t)len * F), o_X = reserve(sizeof(cx<T>) * (size_t)N * S * F);
   const size_t o_est = reserve(sizeof(double) * 2 * F), o_hp = reserve(sizeof(cx<T>) * (size_t)np * F);
   const size_t o_H = reserve(sizeof(cx<T>) * (size_t)nc * F);
+  const size_t o_Xp = reserve(sizeof(cx<T>) * (size_t)np * S * F);
   const size_t o_rho = reserve(sync && n_out > 0 ? sizeof(cx<T>) * (size_t)n_out * F : 0);
   const size_t o_seg = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
   const size_t o_spec = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
@@ -621,6 +734,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   unsigned char* arena = (unsigned char*)pl->ws_t4;
   dres = arena + o_res; dresv = arena + o_resv; dy = arena + o_y; dX = arena + o_X; dest = arena + o_est;
   dhp = arena + o_hp; dH = arena + o_H;
+  void* dXp = arena + o_Xp;
   OFDM_HIP(hipMemsetAsync(dstat, 0, sizeof(int32_t) * F, s));
   OFDM_HIP(hipMemsetAsync(dtg, 0, sizeof(int64_t) * F, s));
   OFDM_HIP(hipMemsetAsync(dfo, 0, sizeof(double) * F, s));
@@ -667,10 +781,10 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     const void* twd = nullptr;
     OFDM_TRY(get_twiddles(N, f64, &twd));
     switch (N / 512) {
-      case 1: OFDM_TRY((t4_demod_launch<T, 1>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
-      case 2: OFDM_TRY((t4_demod_launch<T, 2>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
-      case 4: OFDM_TRY((t4_demod_launch<T, 4>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
-      default: OFDM_TRY((t4_demod_launch<T, 8>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo))); break;
+      case 1: OFDM_TRY((t4_demod_launch<T, 1>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;
+      case 2: OFDM_TRY((t4_demod_launch<T, 2>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;
+      case 4: OFDM_TRY((t4_demod_launch<T, 4>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;
+      default: OFDM_TRY((t4_demod_launch<T, 8>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;
     }
   } else {
     hipLaunchKernelGGL(t4_align_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dy, len, N + Tg, N,
@@ -708,7 +822,8 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   if (sync) {
     OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
     const double deltak = (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0];       // fine_sync.m:6
-    PilotView<T> pv{(const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, N, np, (int64_t)np * S, (int64_t)N * S};
+    PilotView<T> pv{direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, N, np, (int64_t)np * S,
+                    direct ? (int64_t)np * S : (int64_t)N * S, direct ? 1 : 0};
     hipLaunchKernelGGL(fine_tau_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, deltak, 1 /* T4 variant */, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, time_desync, (double*)dest);
     // staged form: rewrite X; otherwise the rotation is applied where X is read (pilot means, equaliser)
@@ -719,10 +834,11 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   }
   const double* lazy_rot = (sync && direct) ? (const double*)dest : nullptr;
   if (mp_desync) {
-    hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s, (const cx<T>*)dX, (const cx<T>*)dtx,
-                       (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S, lazy_rot, time_desync, freq_desync);
-    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), (unsigned)F), dim3(128), 0, s, (const T*)dW, (const cx<T>*)dhp,
-                       (cx<T>*)dH, nc, np);
+    hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s,
+                       direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S,
+                       lazy_rot, time_desync, freq_desync, direct ? 1 : 0);
+    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), 0, s, (const T*)dW,
+                       (const cx<T>*)dhp, (cx<T>*)dH, nc, np, F);
   } else {
     hipLaunchKernelGGL(t4_fill_ones_kernel<T>, dim3(256), dim3(256), 0, s, (cx<T>*)dH, (int64_t)nc * F);
   }
@@ -735,8 +851,8 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   OFDM_TRY(get_twiddles(N, f64, &tw));
   OFDM_TRY(fast_params_prepare<T>(pv2, tw, F, P));
   P.h_in = (const cx<T>*)dH;
-  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, N, true, F, dbits, dref, derr, dh_out, nullptr, lazy_rot, time_desync,
-                           freq_desync));                                                                   // T4:334-347
+  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, direct ? nc : N, true, F, dbits, dref, derr, dh_out, nullptr, lazy_rot,
+                           time_desync, freq_desync));                                                                   // T4:334-347
   return OFDM_OK;
 }
 
@@ -874,13 +990,13 @@ int ofdm_fine_sync(const void* rx, int nfft, int64_t n_symb, const int32_t* pilo
   OFDM_TRY(st.fetch((tau_out || phase_out) ? est : nullptr, sizeof(est), &dest));
   const int64_t total = (int64_t)nfft * n_symb;
   if (f64) {
-    PilotView<double> pv{(const c64*)dx, (const c64*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0};
+    PilotView<double> pv{(const c64*)dx, (const c64*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0, 0};
     hipLaunchKernelGGL(fine_tau_kernel<double>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, deltak, variant, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<double>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, time_desync, (double*)dest);
     hipLaunchKernelGGL(fine_apply_kernel<double>, dim3(ew_grid(total)), dim3(256), 0, ctx().stream, (const c64*)dx,
                        (c64*)dout, nfft, n_symb, time_desync, freq_desync, (const double*)dest);
   } else {
-    PilotView<float> pv{(const c32*)dx, (const c32*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0};
+    PilotView<float> pv{(const c32*)dx, (const c32*)dtx, (const int32_t*)dpc, nfft, n_pilots, (int64_t)n_pilots * n_symb, 0, 0};
     hipLaunchKernelGGL(fine_tau_kernel<float>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, deltak, variant, (double*)dest);
     hipLaunchKernelGGL(fine_phase_kernel<float>, dim3(1), dim3(FS_THREADS), 0, ctx().stream, pv, time_desync, (double*)dest);
     hipLaunchKernelGGL(fine_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, ctx().stream, (const c32*)dx,
