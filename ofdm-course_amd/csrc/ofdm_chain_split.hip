@@ -43,8 +43,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
   // fine_est: the residual timing / phase estimates of fine_sync (tau, phase) per frame; its rotation
   // exp(j (2 pi tau k + phase)) (fine_sync.m:36-43) is applied to every sample as it is read, with the rounding of the
   // separate pass, instead of rewriting X
-  c64* rot = (c64*)smem;                                                // [n_carrier] when fine_est, else empty
-  cx<T>* geq = (cx<T>*)(rot + (fine_est ? P.n_carrier : 0));            // [n_carrier]
+  cx<T>* geq = (cx<T>*)smem;                                            // [n_carrier]
   uint8_t* codes = (uint8_t*)(geq + P.n_carrier);                       // [n_symb * nd] (+ padding to 32)
   __shared__ unsigned int sh_err;
   __shared__ int sh_tidx[FAST_MAXT];
@@ -112,6 +111,10 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
       }
     }
     if (fine_est) {
+      // the fine-sync rotation exp(j (2 pi tau k + phase)) of carrier k (fine_sync.m:23-29, :39-43) is the same for every
+      // symbol of the frame: folded into the equaliser coefficient (formed in double, rounded once) -- one complex multiply
+      // per sample instead of a double-precision rotation and a multiply
+      __syncthreads();                                                // every geq[k] of this frame is in place
       const double tau = fine_est[2 * f], ph = fine_est[2 * f + 1];
       double psn = 0.0, pcs = 1.0;
       if (freq_desync) sincos(ph, &psn, &pcs);
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
           const double t = tau * (double)k;
           sincospi(2.0 * (t - floor(t)), &sn, &cs);
         }
-        rot[k] = c64{cs * pcs - sn * psn, sn * pcs + cs * psn};
+        const double rr = cs * pcs - sn * psn, ri = sn * pcs + cs * psn;
+        const cx<T> g = geq[k];
+        geq[k] = mk<T>((T)((double)g.x * rr - (double)g.y * ri), (T)((double)g.x * ri + (double)g.y * rr));
       }
     }
     __syncthreads();
@@ -147,11 +152,7 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
 #pragma unroll
           for (int u = 0; u < 8; ++u)
             if (dv[u] >= 0 && s0 + v < P.n_symb) {
-              cx<T> xs = xv[v][u];
-              if (fine_est) {
-                const c64 r = rot[k0 + 256 * u];
-                xs = mk<T>((T)((double)xs.x * r.x - (double)xs.y * r.y), (T)((double)xs.x * r.y + (double)xs.y * r.x));
-              }
+              const cx<T> xs = xv[v][u];
               const cx<T> ye = xs * geq[k0 + 256 * u];
               int code;
               if constexpr (BA >= 2) code = demap_square_lut<T, BA>(tab, sh_lut, ye);
@@ -296,8 +297,7 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
   hipStream_t st = ctx().stream;
   DemapTable<T> tab;
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
-  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31)) +
-                     (fine_est ? sizeof(c64) * (size_t)pv.n_carrier : 0);
+  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
   OFDM_ARG(dyn <= 150 * 1024, "rx_chain: equalise / demap stage needs %zu bytes of LDS", dyn);
   auto launch = [&](auto kern) -> int {
     int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);

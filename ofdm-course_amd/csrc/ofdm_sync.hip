@@ -41,15 +41,21 @@ __device__ __forceinline__ acf4 acf_shfl_up(acf4 v, int d) {
 template <typename T>
 __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
                                                           cx<T>* __restrict__ rho, int64_t n_out, int64_t rho_stride = 0,
-                                                          const int64_t* __restrict__ resolved = nullptr) {
-  // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out); frames whose
-  // plateau search already succeeded on a prefix (resolved[2 f + 1] != 0) are skipped
-  if (resolved && resolved[2 * blockIdx.y + 1]) return;
-  x += (int64_t)blockIdx.y * len;
-  rho += (int64_t)blockIdx.y * (rho_stride ? rho_stride : n_out);
+                                                          const int32_t* __restrict__ flist = nullptr,
+                                                          const int32_t* __restrict__ fcount = nullptr) {
+  // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out).  With a frame list
+  // (the frames a prefix of rho did not settle) grid.y strides over the list instead: a launch over an empty list costs
+  // a few hundred idle workgroups, not one per (tile, frame) -- that alone was 60 us per 1024 frames.
   __shared__ acf4 S[ACF_ELEMS + 1];                  // exclusive prefix: S[i] = sum_{m<i}
   __shared__ acf4 wtot[ACF_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const cx<T>* const x_all = x;
+  cx<T>* const rho_all = rho;
+  const int n_list = flist ? *fcount : 1;
+  for (int li = flist ? (int)blockIdx.y : 0; li < n_list; li += flist ? (int)gridDim.y : 1) {
+  const int64_t fr = flist ? (int64_t)flist[li] : (int64_t)blockIdx.y;
+  x = x_all + fr * len;
+  rho = rho_all + fr * (rho_stride ? rho_stride : n_out);
   const int64_t n0 = (int64_t)blockIdx.x * ACF_TILE;
   const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
   const int m_cnt = n_here + W - 1;                  // elements needed: m = n0 .. n0+n_here+W-2
@@ -97,6 +103,15 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
     const double den = sqrt(e1 * e2);                // AutoCorrFunction.m:6
     rho[n0 + i] = mk<T>((T)(pr / den), (T)(pi / den));
   }
+  __syncthreads();                                   // S / wtot are reused by the next listed frame
+  }
+}
+
+// frames whose plateau search did not succeed on the prefix of rho (res[2 f + 1] == 0), in any order
+__global__ void t4_unresolved_kernel(const int64_t* __restrict__ res, int64_t n_frames, int32_t* __restrict__ flist,
+                                     int32_t* __restrict__ fcount) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n_frames && !res[2 * f + 1]) flist[atomicAdd(fcount, 1)] = (int32_t)f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,6 +194,13 @@ __global__ __launch_bounds__(PLAT_THREADS) void first_above_kernel(const cx<T>* 
 constexpr int FS_THREADS = 256;
 
 __device__ __forceinline__ double angle0(double re, double im) { return (re == 0.0 && im == 0.0) ? 0.0 : atan2(im, re); }
+// angle of a pilot product: parity mode in double; throughput mode (fp32 data) with the float atan2 -- the double one is
+// ~150 double-rate instructions and made the two fine-sync reductions compute-bound once their gathers were gone
+template <typename T>
+__device__ __forceinline__ double angle0_t(double re, double im) {
+  if constexpr (sizeof(T) == 4) return (re == 0.0 && im == 0.0) ? 0.0 : (double)atan2f((float)im, (float)re);
+  else return angle0(re, im);
+}
 
 template <typename T>
 struct PilotView {
@@ -199,8 +221,9 @@ struct PilotView {
 };
 
 // taus(i) = angle(q(i+1) conj(q(i))) / (2 pi dk)
+template <typename T>
 __device__ __forceinline__ double tau_of(double ar, double ai, double br, double bi, double inv2pidk) {
-  return angle0(br * ar + bi * ai, bi * ar - br * ai) * inv2pidk;
+  return angle0_t<T>(br * ar + bi * ai, bi * ar - br * ai) * inv2pidk;
 }
 
 // Every thread owns FS_U CONSECUTIVE entries of `taus` per trip: their FS_U + 2 pilot products are requested together
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
       if (i >= 0 && i < (long long)M && i0 < L) pv.q((unsigned)i, qr[u], qi[u]);
     }
     double tp = 0.0;                                             // taus(i0 - 1)
-    if (i0 >= 1 && i0 - 1 < M - 1) tp = tau_of(qr[0], qi[0], qr[1], qi[1], inv);
+    if (i0 >= 1 && i0 - 1 < M - 1) tp = tau_of<T>(qr[0], qi[0], qr[1], qi[1], inv);
     bool keep[FS_U];
     double tv[FS_U];
     int mine = 0;
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
       keep[u] = false;
       tv[u] = 0.0;
       if (i < L) {
-        tv[u] = i < M - 1 ? tau_of(qr[u + 1], qi[u + 1], qr[u + 2], qi[u + 2], inv) : 0.0;      // taus(M) = 0 (T5 form)
+        tv[u] = i < M - 1 ? tau_of<T>(qr[u + 1], qi[u + 1], qr[u + 2], qi[u + 2], inv) : 0.0;      // taus(M) = 0 (T5 form)
         if (i >= 1) {
           const double d = tv[u] - tp;
           keep[u] = fabs(d) < 1e-3;                              // fine_sync.m:18
@@ -322,7 +345,7 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
           const double r2 = qr[u] * cs + qi[u] * sn, i2 = qi[u] * cs - qr[u] * sn;
           qr[u] = r2; qi[u] = i2;
         }
-        const double a = angle0(qr[u], qi[u]);                   // :35
+        const double a = angle0_t<T>(qr[u], qi[u]);              // :35
         if (fabs(a) > 1e-3) { sum += a; cnt += 1; }              // :37
       }
     }
@@ -676,20 +699,34 @@ constexpr int T4_FT = 8;
 template <typename T>
 __global__ __launch_bounds__(128) void t4_apply_operator_kernel(const T* __restrict__ W, const cx<T>* __restrict__ hp,
                                                                 cx<T>* __restrict__ hout, int n_out, int n_in, int64_t n_frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char t4_smem[];
+  cx<T>* hs = (cx<T>*)t4_smem;                                     // [n_in][T4_FT]: the tile's pilot means
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t f0 = (int64_t)blockIdx.y * T4_FT;
+  for (int i = threadIdx.x; i < n_in * T4_FT; i += blockDim.x) {
+    const int f = i / n_in, j = i - f * n_in;
+    hs[j * T4_FT + f] = f0 + f < n_frames ? hp[(f0 + f) * n_in + j] : mk<T>(0, 0);
+  }
+  __syncthreads();
   if (m >= n_out) return;
   double ar[T4_FT], ai[T4_FT];
 #pragma unroll
   for (int f = 0; f < T4_FT; ++f) ar[f] = ai[f] = 0.0;
-  for (int j = 0; j < n_in; ++j) {
-    const double w = (double)W[(size_t)j * n_out + m];
+  for (int j0 = 0; j0 < n_in; j0 += 8) {                           // eight weights of the column in flight
+    T w[8];
 #pragma unroll
-    for (int f = 0; f < T4_FT; ++f) {
-      const int64_t ff = f0 + f < n_frames ? f0 + f : n_frames - 1;
-      const cx<T> z = hp[ff * n_in + j];
-      ar[f] += w * (double)z.x;
-      ai[f] += w * (double)z.y;
+    for (int u = 0; u < 8; ++u) w[u] = j0 + u < n_in ? W[(size_t)(j0 + u) * n_out + m] : T(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < n_in) {
+        const double wd = (double)w[u];
+#pragma unroll
+        for (int f = 0; f < T4_FT; ++f) {
+          const cx<T> z = hs[(j0 + u) * T4_FT + f];
+          ar[f] += wd * (double)z.x;
+          ai[f] += wd * (double)z.y;
+        }
+      }
     }
   }
 #pragma unroll
@@ -725,6 +762,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   const size_t o_seg = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
   const size_t o_spec = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
   const size_t o_first = reserve(freq_desync ? sizeof(int64_t) * F : 0);
+  const size_t o_flist = reserve(sizeof(int32_t) * (F + 1));
   if (pl->ws_t4_bytes < need) {
     OFDM_HIP(hipStreamSynchronize(s));
     if (pl->ws_t4) { (void)hipFree(pl->ws_t4); pl->ws_t4 = nullptr; pl->ws_t4_bytes = 0; }
@@ -750,12 +788,20 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     const bool two_pass = n_pref < n_out && !getenv("OFDM_T4_FULL_ACF");
     if (two_pass) {
       hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_pref, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
-                         N, (cx<T>*)drho, n_pref, n_out, (const int64_t*)nullptr);
+                         N, (cx<T>*)drho, n_pref, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
       hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_pref, Tg, 0.77,
                          (int64_t*)dres, (double*)dresv, n_out, 0);
     }
-    hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
-                       N, (cx<T>*)drho, n_out, n_out, two_pass ? (const int64_t*)dres : (const int64_t*)nullptr);
+    if (two_pass) {
+      int32_t* dfl = (int32_t*)(arena + o_flist);                // [0] = count, [1..] = frames still to do
+      OFDM_HIP(hipMemsetAsync(dfl, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(t4_unresolved_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, F, dfl + 1, dfl);
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)std::min<int64_t>(F, 8)), dim3(ACF_THREADS), 0, s,
+                         (const cx<T>*)drx, len, Tg, N, (cx<T>*)drho, n_out, n_out, (const int32_t*)(dfl + 1), (const int32_t*)dfl);
+    } else {
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
+                         N, (cx<T>*)drho, n_out, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    }
     hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
                        (int64_t*)dres, (double*)dresv, n_out, two_pass ? 1 : 0);
     hipLaunchKernelGGL(t4_scalars_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, (const double*)dresv, n_out,
@@ -837,7 +883,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s,
                        direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S,
                        lazy_rot, time_desync, freq_desync, direct ? 1 : 0);
-    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), 0, s, (const T*)dW,
+    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), sizeof(cx<T>) * np * T4_FT, s, (const T*)dW,
                        (const cx<T>*)dhp, (cx<T>*)dH, nc, np, F);
   } else {
     hipLaunchKernelGGL(t4_fill_ones_kernel<T>, dim3(256), dim3(256), 0, s, (cx<T>*)dH, (int64_t)nc * F);
