@@ -230,6 +230,22 @@ int ofdm_rx_chain_task4(ofdm_rx_plan* plan, const void* rx, int64_t n_frames, in
 int ofdm_tx_frames(ofdm_rx_plan* plan, const void* h, int h_len, double snr_db, int noise_on, uint64_t seed,
                    int64_t frame0, int64_t n_frames, void* rx_out, uint8_t* ref_bits_out, uint8_t* bits_out, int flags);
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
+/* One tile of the Monte-Carlo study of T5/Task5_part2.m:148-205, :269-304: n_frames channel realisations jj of the plan's
+ * pilot scenario kk, all four estimators on every realisation, nothing but sums returned.
+ *   tx_noised[(nfft+t_guard)*n_symb]: the scenario's noisy TX stream (:130-134; DEVICE or HOST per flags);
+ *   tap_delay[n_frames][n_ch_taps] (0-based sample delays), tap_amp[n_frames][n_ch_taps] (interleaved complex double):
+ *   the realisation's channel (what :150-155 hand to conv, :160-166) -- HOST arrays;
+ *   ref_bits: the scenario's packed payload bits, ONE frame (layout of ofdm_rx_chain_task5; all realisations share the TX).
+ * Per realisation: conv + truncate, OFDM_demodulator, LS_CE (:174), MMSE_CE with h = the true CIR and snr_db (:176-177),
+ * MP_estimate and OMP_estimate with dominant_taps = the plan's (:192-193; the plan's K = the dictionary's columns),
+ * NMSE of each against fft(h) on carriers 1..N_carrier (:202-205), equalize_signal / get_payload / demapping / BER_func
+ * for each (:269-304).
+ *   nmse_out[4][n_frames] (double), errors_out[4][n_frames] (uint32 bit errors): rows LS, MMSE, MP, OMP.
+ * The MP projections S^H * residue run as one real GEMM per iteration on the matrix cores in fp32 when Np is a multiple of
+ * 16 (dense dictionaries of random pilot masks, :58-64).  At most 65535 realisations and 64 channel taps per call. */
+int ofdm_task5_part2_tile(ofdm_rx_plan* plan, const void* tx_noised, const int32_t* tap_delay, const double* tap_amp,
+                          int n_ch_taps, int64_t n_frames, double snr_db, const uint8_t* ref_bits, double* nmse_out,
+                          uint32_t* errors_out, int flags);
 /* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
  * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call
  * (comb pilot layouts run the first two as one launch and report {symbol-1 + OMP kernel, 0, symbols

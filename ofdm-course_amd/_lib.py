@@ -74,6 +74,7 @@ SIGNATURES = {
     "ofdm_rx_plan_set_timing": [_vp, _i],
     "ofdm_rx_plan_last_kernel_ms": [_vp, C.POINTER(C.c_float)],
     "ofdm_rx_chain_task5": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i],
+    "ofdm_task5_part2_tile": [_vp, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp, _i],
 }
 _RESTYPES = {"ofdm_last_error_string": C.c_char_p, "ofdm_rx_plan_frame_bytes": C.c_int64}
 

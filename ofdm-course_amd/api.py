@@ -35,7 +35,7 @@ __all__ = [
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
     "add_CFO", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
-    "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "DEFAULT_REGISTER",
+    "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "task5_part2_tile", "DEFAULT_REGISTER",
 ]
 
 DEFAULT_REGISTER = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)   # T5/Main_model_Task_5.m:55
@@ -770,3 +770,37 @@ def rx_chain_task4(plan: RxPlan, rx, time_desync=1, freq_desync=1, mp_desync=1, 
                                          int(bool(mp_desync)), pbits, pref, perr, ptg, pfo, pifo, pst, pH, call.flags),
             "rx_chain_task4")
     return dict(bits=bits, errors=errors, TgPosition=tg, FreqOffset=fo, IFO=ifo, status=stt, H=H)
+
+
+def task5_part2_tile(plan: RxPlan, tx_noised, taps_list, SNR_dB, ref_bits_packed):
+    """One tile of T5/Task5_part2.m:148-205, :269-304: every channel realisation of `taps_list` (each a [(delay, amplitude)]
+    array like `channel_taps`, all of the same length) applied to the scenario's noisy TX stream `tx_noised`, then LS_CE,
+    MMSE_CE (h = the true CIR, SNR_dB), MP_estimate and OMP_estimate (dominant_taps = the plan's), their NMSE against
+    fft(h) and the four equalise / demap / BER passes -- one device-resident pass, only the sums come back.
+
+    ref_bits_packed: the scenario's payload, ONE packed frame [frame_bytes] (every realisation shares the TX frame).
+    Returns dict(nmse=[4, n] float64, errors=[4, n] uint32) with rows LS, MMSE, MP, OMP."""
+    call = _Call(tx_noised, f64=plan.f64)
+    n = len(taps_list)
+    t0 = np.asarray(taps_list[0])
+    T = t0.shape[0]
+    delay = np.empty((n, T), dtype=np.int32)
+    amp = np.empty((n, T), dtype=np.complex128)
+    for i, t in enumerate(taps_list):
+        t = np.asarray(t)
+        if t.shape[0] != T:
+            raise OfdmError("task5_part2_tile: every realisation needs the same number of channel taps")
+        delay[i] = np.real(t[:, 0]).astype(np.int32)
+        amp[i] = t[:, 1]
+    ref = ref_bits_packed
+    ref = ref.contiguous().view(-1) if _is_torch(ref) else np.ascontiguousarray(ref).reshape(-1)
+    if ref.shape[0] != plan.frame_bytes:
+        raise OfdmError("task5_part2_tile: ref_bits_packed must be one packed frame")
+    pref = call._flat(ref, np.uint8, torch.uint8 if call.dev else None)[0]
+    nm, pnm = call._out((n, 4), np.float64, torch.float64 if call.dev else None)      # memory [4][n]
+    er, per = call._out((n, 4), np.uint32, torch.int32 if call.dev else None)
+    ampv = np.ascontiguousarray(amp).view(np.float64)
+    L.check(call.lib.ofdm_task5_part2_tile(plan.handle, call.cin(tx_noised), C.c_void_p(delay.ctypes.data),
+                                           C.c_void_p(ampv.ctypes.data), T, n, float(SNR_dB), pref, pnm, per, call.flags),
+            "task5_part2_tile")
+    return dict(nmse=nm.T, errors=er.T)

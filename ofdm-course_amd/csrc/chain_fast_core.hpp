@@ -362,6 +362,80 @@ __device__ __forceinline__ void omp_frame_reg(const FastParams<T>& P, const cx<T
   }
 }
 
+// ---- dictionary correlation on the matrix cores: c0f (complex, row stride cs) [FB][16 n_tiles] = conj-dictionary^T * Y for
+// the FB frames staged in LDS (Yl rows of YS elements, np pilots), columns 0 .. 16 n_tiles - 1 of sct ([np][ks], atom
+// fastest).  One 256-thread workgroup (wave = 0..3).  Shared by the batch OMP (c0 = S^H Y) and the batch MP (S^H residue per
+// iteration, MP_estimate.m:15).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void corr_mfma_f32(const cx<float>* __restrict__ sct, int ks, int n_tiles,
+                                              const cx<float>* __restrict__ Yl, int YS, int np, int FB,
+                                              float* __restrict__ c0f, int cs, int wave, int lane) {
+    // real GEMM  C[K x 2 FB] = A[K x 2np] * B[2np x 2 FB]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
+    // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
+    // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 per 16x16 tile (real / imaginary parts of A).
+    // A: lane (i = lane&15, q = lane>>4) supplies sct[p0+q][16*tile + i], loaded once per k-step and reused
+    // for every 16-column group; B: lane (n = lane&15, q) supplies column n at pilot p0+q (LDS).
+    // C: lane holds rows 4*(lane>>4)+r of column lane&15.
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fsub = i16 >> 1, cim = i16 & 1;
+    const int n_cg = (FB + 7) / 8;                 // 16-column groups (8 frames each): 1, 2 or 4 (FB = 4: half of one)
+    for (int tile0 = wave * 2; tile0 < n_tiles; tile0 += 8) {
+      const bool two = tile0 + 1 < n_tiles;
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
+      const cx<float>* a0p = sct + tile0 * 16 + i16;
+      // The A operands come from L2 (the dictionary is shared by every workgroup); PD k-steps are kept in flight in
+      // statically indexed registers (the loop is unrolled by PD): with one step in flight the stage was bound by
+      // one L2 round trip per 4 pilots.
+      constexpr int PD = 4;
+      cx<float> aq0[PD], aq1[PD];
+#pragma unroll
+      for (int d = 0; d < PD; ++d) {
+        const int pl = 4 * d < np ? 4 * d : 0;
+        aq0[d] = a0p[(size_t)(pl + q) * ks];
+        aq1[d] = two ? a0p[(size_t)(pl + q) * ks + 16] : mk<float>(0, 0);
+      }
+      for (int pb = 0; pb < np; pb += 4 * PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int p0 = pb + 4 * d;
+          if (p0 >= np) break;                                   // uniform
+          const cx<float> a0 = aq0[d], a1 = aq1[d];
+          const int pn = p0 + 4 * PD < np ? p0 + 4 * PD : p0;    // refill this slot for PD steps ahead
+          aq0[d] = a0p[(size_t)(pn + q) * ks];
+          aq1[d] = two ? a0p[(size_t)(pn + q) * ks + 16] : mk<float>(0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (g < n_cg) {
+              const cx<float> yv = g * 8 + fsub < FB ? Yl[(g * 8 + fsub) * YS + p0 + q] : mk<float>(0, 0);
+              const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
+              const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
+              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc[0][g], 0, 0, 0);
+              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc[0][g], 0, 0, 0);
+              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc[1][g], 0, 0, 0);
+              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc[1][g], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < n_cg) {
+          const int fcol = g * 8 + fsub;
+          if (fcol >= FB) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c0f[2 * (fcol * cs + tile0 * 16 + 4 * q + r) + cim] = acc[0][g][r];
+            if (two) c0f[2 * (fcol * cs + (tile0 + 1) * 16 + 4 * q + r) + cim] = acc[1][g][r];
+          }
+        }
+      }
+    }
+}
+
 // Resident workgroups per CU of a persistent kernel (occupancy API: registers + LDS), cached per
 // (kernel, dynamic LDS size); also raises the kernel's dynamic-LDS limit to `dyn`.  Workgroups are
 // independent, so an optimistic answer only queues a few of them.

@@ -86,8 +86,6 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 //            and the refit is spread over the group's lanes with R = L^-1 updated in place.
 //            Solve arithmetic is in the data precision T (double in parity mode).
 // ---------------------------------------------------------------------------------------------
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
 struct OmpLayout {          // byte offsets into dynamic LDS
   unsigned off_y, off_c0, off_gram, off_state, off_fft, state_bytes, total;
   int fpw;                  // frames per wavefront
@@ -167,72 +165,7 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
       }
     }
   } else if constexpr (MFMA) {
-    // real GEMM  C[K x 2 FB] = A[K x 2np] * B[2np x 2 FB]:  A = [Re sct | Im sct]^T, column 2f = Re c0(f),
-    // column 2f+1 = Im c0(f):  B(p,re ; 2f) = Yr, B(p,im ; 2f) = -Yi, B(p,re ; 2f+1) = Yi, B(p,im ; 2f+1) = Yr.
-    // One k-step = 4 pilots -> two v_mfma_f32_16x16x4_f32 per 16x16 tile (real / imaginary parts of A).
-    // A: lane (i = lane&15, q = lane>>4) supplies sct[p0+q][16*tile + i], loaded once per k-step and reused
-    // for every 16-column group; B: lane (n = lane&15, q) supplies column n at pilot p0+q (LDS).
-    // C: lane holds rows 4*(lane>>4)+r of column lane&15.
-    const int i16 = lane & 15, q = lane >> 4;
-    const int fsub = i16 >> 1, cim = i16 & 1;
-    const int n_tiles = K / 16;
-    const int n_cg = (FB + 7) / 8;                 // 16-column groups (8 frames each): 1, 2 or 4 (FB = 4: half of one)
-    for (int tile0 = wave * 2; tile0 < n_tiles; tile0 += 8) {
-      const bool two = tile0 + 1 < n_tiles;
-      f32x4 acc[2][4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
-      const cx<T>* a0p = P.sct + tile0 * 16 + i16;
-      // The A operands come from L2 (the dictionary is shared by every workgroup); PD k-steps are kept in flight in
-      // statically indexed registers (the loop is unrolled by PD): with one step in flight the stage was bound by
-      // one L2 round trip per 4 pilots.
-      constexpr int PD = 4;
-      cx<T> aq0[PD], aq1[PD];
-#pragma unroll
-      for (int d = 0; d < PD; ++d) {
-        const int pl = 4 * d < np ? 4 * d : 0;
-        aq0[d] = a0p[(size_t)(pl + q) * K];
-        aq1[d] = two ? a0p[(size_t)(pl + q) * K + 16] : mk<T>(0, 0);
-      }
-      for (int pb = 0; pb < np; pb += 4 * PD) {
-#pragma unroll
-        for (int d = 0; d < PD; ++d) {
-          const int p0 = pb + 4 * d;
-          if (p0 >= np) break;                                   // uniform
-          const cx<T> a0 = aq0[d], a1 = aq1[d];
-          const int pn = p0 + 4 * PD < np ? p0 + 4 * PD : p0;    // refill this slot for PD steps ahead
-          aq0[d] = a0p[(size_t)(pn + q) * K];
-          aq1[d] = two ? a0p[(size_t)(pn + q) * K + 16] : mk<T>(0, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (g < n_cg) {
-              const cx<T> yv = g * 8 + fsub < FB ? Yl[(g * 8 + fsub) * YS + p0 + q] : mk<T>(0, 0);
-              const float b_re = cim ? yv.y : yv.x;        // multiplies Re(sct)
-              const float b_im = cim ? yv.x : -yv.y;       // multiplies Im(sct)
-              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b_re, acc[0][g], 0, 0, 0);
-              acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b_im, acc[0][g], 0, 0, 0);
-              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b_re, acc[1][g], 0, 0, 0);
-              acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b_im, acc[1][g], 0, 0, 0);
-            }
-          }
-        }
-      }
-      float* c0f = (float*)c0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < n_cg) {
-          const int fcol = g * 8 + fsub;
-          if (fcol >= FB) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            c0f[2 * (fcol * K + tile0 * 16 + 4 * q + r) + cim] = acc[0][g][r];
-            if (two) c0f[2 * (fcol * K + (tile0 + 1) * 16 + 4 * q + r) + cim] = acc[1][g][r];
-          }
-        }
-      }
-    }
+    corr_mfma_f32(P.sct, K, K / 16, Yl, YS, np, FB, (float*)c0, K, wave, lane);
   } else {
     for (int i = tid; i < FB * K; i += 256) {
       const int f = i / K, k = i - f * K;

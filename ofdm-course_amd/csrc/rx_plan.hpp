@@ -32,6 +32,7 @@ struct ofdm_rx_plan {
   void* d_t4_w = nullptr;
   void* ws_t4 = nullptr;   // ofdm_rx_chain_task4: arena for its per-batch intermediates
   size_t ws_t4_bytes = 0;
+  void* d_p2_sop = nullptr; // ofdm_task5_part2_tile: spline operator of interpolate.m [n_carrier x np], double
 };
 
 // view of a plan for the fast / split stages

@@ -40,9 +40,13 @@ def random_pilot_layout(Nfft, N_carrier, amount_pilots, seed):
 
 def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_SpF=7, Constellation="16QAM",
         monteCarloRuns=100, SNR_dB=20, combs=None, DelayProfile="EPA", SamplingRate=4e7, seed=5, rank=0, world=1,
-        reg_pilot=1, Nps=None):
+        reg_pilot=1, Nps=None, batched=None, precision="fp64"):
     """T5/Task5_part2.m:4-320.  reg_pilot = 1 (:12): one scenario per comb; reg_pilot = 0: one scenario per pilot
-    count `Nps` (:21, default = the regular study's counts) on a random mask, dictionary = all Nfft delays (:181-184)."""
+    count `Nps` (:21, default = the regular study's counts) on a random mask, dictionary = all Nfft delays (:181-184).
+
+    batched: run this rank's realisations of a scenario as ONE device-resident tile (`lib.task5_part2_tile`: all four
+    estimators, NMSE sums and BER counters on the device) instead of call by call; default = whenever the library has
+    that entry (the HIP library does, the oracle adapter of the tests does not).  precision: of the batched tile."""
     lib = lib or c.default_lib()
     T_Guard = Nfft // 8
     N_symb = Amount_OFDM_Frames * Amount_ODFM_SpF
@@ -74,6 +78,23 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
         X = lib.OFDM_map_carriers(TX_IQ, N_symb, Nfft, dataCarriers, pilotCarriers, pilotValues)   # :123
         Tx = np.asarray(lib.OFDM_modulator(X, T_Guard)).ravel(order="F")            # :130-132
         Tx_noised, _ = lib.Noise(SNR_dB, Tx, seed=seed, stream=kk)                  # :134 (noise BEFORE the channel)
+        mine = [jj for jj in range(monteCarloRuns) if (kk * monteCarloRuns + jj) % world == rank]
+        use_tile = (batched if batched is not None else hasattr(lib, "task5_part2_tile")) and len(mine) > 0
+        if use_tile:
+            # :148-304 for all of this rank's realisations of scenario kk in one call
+            from .. import frames as fr
+            taps_l = [c.fading_taps(DelayProfile, SamplingRate, channel_Seeds[kk, jj]) for jj in mine]   # :150-152
+            plan = lib.RxPlan(Nfft, T_Guard, N_symb, N_carrier, pilotCarriers, dataCarriers, pilotValues[:, 0], K,
+                              taps_l[0].shape[0], Constellation, precision=precision)
+            cdt = np.complex128 if precision == "fp64" else np.complex64
+            out = lib.task5_part2_tile(plan, np.asarray(Tx_noised).astype(cdt), taps_l, SNR_dB,
+                                       fr.pack_bits(np.asarray(input_bits)[None, :])[0])
+            nmse_sum[:, kk] += np.asarray(out["nmse"]).sum(axis=1)
+            err_sum[:, kk] += np.asarray(out["errors"]).astype(np.int64).sum(axis=1)
+            bit_sum[kk] += input_bits.size * len(mine)
+            runs[kk] += len(mine)
+            plan.close()
+            continue
         S = lib.sensing_matrix(pilotCarriers, Nfft, K)                              # :181-189 closed form
         for jj in range(monteCarloRuns):                                            # :148
             if (kk * monteCarloRuns + jj) % world != rank:
