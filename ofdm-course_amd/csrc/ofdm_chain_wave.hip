@@ -36,7 +36,8 @@ constexpr int WV_WPB = 4;              // wavefronts (= frames in flight) per wo
 
 // dynamic LDS: W_2048 table [31][64] | W_64 table [7][64] | data positions [4][64] (8-byte stride) | per-wave regions
 constexpr unsigned WV_OFF_TW = 0, WV_OFF_TWB = 8 * 64 * WV_TW_ROWS, WV_OFF_DD = WV_OFF_TWB + 8 * 64 * 7;
-constexpr unsigned WV_OFF_WAVE = WV_OFF_DD + 8 * 64 * 4;
+constexpr unsigned WV_OFF_LUT = WV_OFF_DD + 8 * 64 * 4;              // decision thresholds of demap_square_lut
+constexpr unsigned WV_OFF_WAVE = WV_OFF_LUT + 256;
 constexpr unsigned WV_TRASH_OFF = 8 * WV_TR_ELEMS, WV_CODES_OFF = WV_TRASH_OFF + 8 * 64;
 struct WaveLayout {
   unsigned wave_bytes, total;
@@ -60,7 +61,15 @@ __device__ __forceinline__ cx<float> w32(int m) {
   }
 }
 
-template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true>
+// LUT: level rank by arithmetic guess + the two neighbouring thresholds from LDS (demap_square_lut) instead of counting all
+// 2^BA - 1 thresholds
+template <int BA, bool LUT>
+__device__ __forceinline__ int slice_wave(const DemapTable<float>& tab, const float* lut, cx<float> z) {
+  if constexpr (LUT && BA >= 2) return demap_square_lut<float, BA>(tab, lut, z);
+  else return slice_symbol<float, BA>(tab, z);
+}
+
+template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, bool LUT = false>
 __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_kernel(FastParams<float> P, WaveLayout lay,
                                                                   const cx<float>* __restrict__ rx, int64_t n_frames,
                                                                   uint32_t* __restrict__ bits_out,
@@ -107,6 +116,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
       *(unsigned*)(smem + WV_OFF_DD + 512 * r + lane8) = d0 | (d1 << 16);
     }
   }
+  const T* const lut = (const T*)(smem + WV_OFF_LUT);
+  if constexpr (BA >= 2) demap_lut_fill<T, BA>(tab, (T*)(smem + WV_OFF_LUT), threadIdx.x);
   __syncthreads();                                                     // the only workgroup barrier of the kernel
   // wave-private region: transposes [576 complex] | 64 spare 8-byte slots | codes
   const unsigned wbase = WV_OFF_WAVE + (unsigned)wave * lay.wave_bytes;
@@ -190,8 +201,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
     // ---- symbol 1 from the stash of the pilot stage
 #pragma unroll
     for (int t = 0; t < 8; ++t)
-      *code_ptr(codes, t) = (uint8_t)slice_symbol<T, BA>(
-          tab, (kk_of(t) < n_carrier ? P.stash[f * n_carrier + kk_of(t)] : mk<T>(0, 0)) * geq[t]);
+      *code_ptr(codes, t) = (uint8_t)slice_wave<BA, LUT>(
+          tab, lut, (kk_of(t) < n_carrier ? P.stash[f * n_carrier + kk_of(t)] : mk<T>(0, 0)) * geq[t]);
     unsigned err = 0;
     int slot = 1;                                                      // symbols in the codes buffer
     int64_t code0 = 0;                                                 // first code index of the buffer within the frame
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
         dft8_first2<T>(u);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-          *code_ptr(cslot, 2 * r + kb) = (uint8_t)slice_symbol<T, BA>(tab, u[kb] * geq[2 * r + kb]);
+          *code_ptr(cslot, 2 * r + kb) = (uint8_t)slice_wave<BA, LUT>(tab, lut, u[kb] * geq[2 * r + kb]);
       }
       ++slot;
       // ---- pack a full batch (or the frame's last one): bit i of the frame -> byte i/8, bit 7 - i%8; BER numerator
@@ -334,10 +345,11 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
     return OFDM_OK;
   };
   const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
-  const bool nowb = getenv("OFDM_WAVE_NO_WBUF") != nullptr;
+  const bool nowb = getenv("OFDM_WAVE_NO_WBUF") != nullptr, uselut = getenv("OFDM_WAVE_LUT") != nullptr;   // LUT slicer: measured 3 % slower at 64-QAM here (7 thresholds per axis)
 #define WAVE_CASE(BAV, HX)                                                                \
   if (wpb == 8) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 8>));                     \
   else if (nowb) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, false>));          \
+  else if (uselut) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, true>));   \
   else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4>))
   if (mmse) {
     switch (ba) {

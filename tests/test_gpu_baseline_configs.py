@@ -151,10 +151,25 @@ def test_c5_snr_sweep_tiles(ofdm, oracle):
     cfg.SNR_dB = snrs[2]
     seed, stream0 = sweep.tile_seed_stream(7, 2, 0, fpt)
     data = fr.make_frames(cfg, ofdm, fpt, seed=seed, precision="fp32", frame0=stream0)
-    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True)
+    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=True)
     ref = oracle.rx_chain_task5(np.asarray(data["rx"]).astype(np.complex128), cfg.Nfft, cfg.T_guard, cfg.N_carrier,
                                 cfg.pilotCarriers, cfg.dataCarriers, data["pilots"], cfg.K, cfg.dominant_taps,
                                 cfg.Constellation, ref_bits=data["bits"])
-    assert rel_l2(np.asarray(out["H"]).T, ref["H"]) < 5e-3
-    ge, oe = np.asarray(out["errors"]).astype(np.int64).sum(), ref["errors"].sum()
-    assert abs(int(ge) - int(oe)) <= 0.02 * max(int(oe), 50)
+    # every device pick is the float64 arg-max or within 1e-4 of it (tests/pick_audit.py); H is the refit on them
+    from pick_audit import omp_pick_audit
+    Smat = oracle.sensing_matrix(cfg.pilotCarriers, cfg.Nfft, cfg.K)
+    pc = np.asarray(cfg.pilotCarriers, int) - 1
+    L = cfg.Nfft + cfg.T_guard
+    idx, H = np.asarray(out["index"]).T, np.asarray(out["H"]).T
+    near_total, exact_frames = 0, 0
+    for f in range(fpt):
+        got = [int(k) for k in idx[f] if k > 0]
+        X1 = oracle.OFDM_demodulator(np.asarray(data["rx"])[:L, f].astype(np.complex128)[:, None], cfg.T_guard)
+        near, H_refit = omp_pick_audit(oracle, X1[pc, 0] / data["pilots"], Smat, got, cfg.Nfft)
+        near_total += near
+        assert rel_l2(H[f], H_refit[:cfg.N_carrier]) < 2e-4, f
+        if near == 0:
+            exact_frames += 1
+            assert got == list(ref["index"][f])[: len(got)] and rel_l2(H[f], ref["H"][f]) < 2e-4
+            assert abs(int(np.asarray(out["errors"])[f]) - int(ref["errors"][f])) <= 4
+    print(f"C5 sweep tile fp32: {near_total} near-tied picks in {fpt} frames, {exact_frames} frames pick-identical")
