@@ -388,6 +388,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
            "rx_plan_create: needs 1 <= taps <= %d, taps <= K <= Nfft", CH_MAXT);
   OFDM_ARG(dominant_taps <= nfft / 8, "rx_plan_create: taps exceed the group size");
   ofdm_rx_plan* pl = new ofdm_rx_plan();
+  pl->device = ctx().device;
   pl->nfft = nfft; pl->t_guard = t_guard; pl->n_symb = n_symb; pl->n_carrier = n_carrier; pl->np = n_pilots;
   pl->nd = n_data; pl->k_atoms = k_atoms; pl->taps = dominant_taps; pl->f64 = is_f64(flags) ? 1 : 0;
   pl->d_prole = pl->d_drole = pl->d_pilots = pl->d_sct = pl->d_gram = pl->d_pc0 = nullptr;
@@ -469,6 +470,7 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
     }
   }
   if (rc != OFDM_OK) { ofdm_rx_plan_destroy(pl); return rc; }
+  ctx().live_plans += 1;
   *plan_out = pl;
   return OFDM_OK;
 }
@@ -480,6 +482,7 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
                   pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx().ready && ctx().device == pl->device && ctx().live_plans > 0) ctx().live_plans -= 1;
   delete pl;
   return OFDM_OK;
 }
@@ -546,6 +549,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
                         const uint8_t* ref_bits, uint32_t* errors_out, void* h_out, int32_t* index_out, int flags) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(pl && rx && n_frames >= 0, "rx_chain_task5: bad arguments");
+  OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "rx_chain_task5: precision flag differs from the plan's");
   OFDM_ARG(!errors_out || ref_bits, "rx_chain_task5: errors_out needs ref_bits");
   if (n_frames == 0) return OFDM_OK;

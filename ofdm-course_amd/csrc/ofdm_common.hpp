@@ -106,10 +106,13 @@ struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
   int num_cu = 256;
+  int live_plans = 0;      // RX plans created on `device` and not yet destroyed (they pin the context to that device)
   // twiddle tables keyed by (nfft << 1 | is_f64): tw[m] = exp(-2*pi*i*m/nfft), m < nfft
   std::map<int64_t, void*> twiddles;
   // scratch pool for host staging (freed at shutdown)
-  struct Block { void* p; size_t bytes; bool busy; };
+  // ev: recorded on the launch stream when a device-flavour call hands the block back (its kernels may still be
+  // running); the block is reusable once the event has completed -- the call itself does not wait
+  struct Block { void* p; size_t bytes; bool busy; hipEvent_t ev = nullptr; bool pending = false; };
   std::vector<Block> pool;
   std::mutex mu;
 };
@@ -117,6 +120,7 @@ Context& ctx();
 int ensure_init();
 int pool_get(size_t bytes, void** out);
 void pool_put(void* p);
+void pool_put_after_stream(void* p);   // hand back a block that work already queued on ctx().stream still uses
 // returns device pointer to exp(-2*pi*i*m/n) table (m<n) in the requested precision
 int get_twiddles(int n, bool f64, const void** out);
 

@@ -41,9 +41,12 @@ int pool_get(size_t bytes, void** out) {
   std::lock_guard<std::mutex> lk(c.mu);
   int best = -1;
   for (size_t i = 0; i < c.pool.size(); ++i) {
-    if (!c.pool[i].busy && c.pool[i].bytes >= bytes &&
-        (best < 0 || c.pool[i].bytes < c.pool[best].bytes))
-      best = (int)i;
+    if (c.pool[i].busy || c.pool[i].bytes < bytes) continue;
+    if (c.pool[i].pending) {                                   // handed back while its last kernels were still queued
+      if (hipEventQuery(c.pool[i].ev) != hipSuccess) continue;
+      c.pool[i].pending = false;
+    }
+    if (best < 0 || c.pool[i].bytes < c.pool[best].bytes) best = (int)i;
   }
   if (best >= 0 && c.pool[best].bytes <= 2 * bytes + 4096) {
     c.pool[best].busy = true;
@@ -73,6 +76,23 @@ void pool_put(void* p) {
   std::lock_guard<std::mutex> lk(c.mu);
   for (auto& b : c.pool)
     if (b.p == p) { b.busy = false; return; }
+}
+
+void pool_put_after_stream(void* p) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (auto& b : c.pool)
+    if (b.p == p) {
+      if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) b.ev = nullptr;
+      if (b.ev && hipEventRecord(b.ev, c.stream) == hipSuccess) {
+        b.pending = true;
+      } else {
+        (void)hipStreamSynchronize(c.stream);                      // no event: fall back to waiting
+        b.pending = false;
+      }
+      b.busy = false;
+      return;
+    }
 }
 
 int get_twiddles(int n, bool f64, const void** out) {
@@ -179,9 +199,11 @@ int Stage::finish() {
 
 void Stage::release() {
   if (!bufs_.empty()) {
-    // pool buffers may still be in flight on the stream in device mode
-    if (dev_) (void)hipStreamSynchronize(ctx().stream);
-    for (void* b : bufs_) pool_put(b);
+    // device flavour: the call's kernels may still be queued on the stream -- the blocks go back with an event recorded
+    // behind them and become reusable when it has completed; the call does not wait (host flavour: finish() has synchronised)
+    for (void* b : bufs_) {
+      if (dev_) pool_put_after_stream(b); else pool_put(b);
+    }
     bufs_.clear();
   }
 }
@@ -267,6 +289,13 @@ int ofdm_init(int device_id) {
   }
   OFDM_ARG(device_id < n, "ofdm_init: device %d out of range (%d devices)", device_id, n);
   if (c.ready && c.device == device_id) return OFDM_OK;
+  if (c.ready && c.live_plans > 0) {
+    // one device per process: live plans hold tables, workspaces and twiddles on c.device -- re-initialising under them
+    // would free the caches they launch with and aim their launches at another GPU
+    set_error("ofdm_init: the context belongs to device %d with %d live RX plan(s); destroy them (or call ofdm_shutdown) "
+              "before switching to device %d -- one device per process", c.device, c.live_plans, device_id);
+    return OFDM_ERR_STATE;
+  }
   if (c.ready) ofdm_shutdown();
   OFDM_HIP(hipSetDevice(device_id));
   hipDeviceProp_t prop;
@@ -284,11 +313,14 @@ int ofdm_shutdown(void) {
   (void)hipDeviceSynchronize();
   for (auto& kv : c.twiddles) (void)hipFree(kv.second);
   c.twiddles.clear();
-  for (auto& b : c.pool)
+  for (auto& b : c.pool) {
     if (b.p) (void)hipFree(b.p);
+    if (b.ev) (void)hipEventDestroy(b.ev);
+  }
   c.pool.clear();
   c.ready = false;
   c.device = -1;
+  c.live_plans = 0;
   return OFDM_OK;
 }
 

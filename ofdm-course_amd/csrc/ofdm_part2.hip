@@ -424,6 +424,7 @@ extern "C" int ofdm_task5_part2_tile(ofdm_rx_plan* pl, const void* tx_noised, co
                                      uint32_t* errors_out, int flags) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(pl && tx_noised && tap_delay && tap_amp && ref_bits && nmse_out && errors_out, "task5_part2_tile: null argument");
+  OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "task5_part2_tile: precision flag differs from the plan's");
   OFDM_ARG(pl->pilots_in_band && pl->np >= 2, "task5_part2_tile: needs at least two pilots, all inside 1..N_carrier");
   OFDM_ARG(n_ch_taps >= 1 && n_ch_taps <= 64 && n_frames >= 0 && n_frames <= 65535, "task5_part2_tile: 1..64 channel taps, at most 65535 realisations");

@@ -9,6 +9,7 @@ struct ofdm_rx_plan {
   int nfft, t_guard, n_symb, n_carrier, np, nd, k_atoms, taps, bps, f64;
   int frame_words;
   int pilots_in_band;
+  int device = -1;         // the device the plan's buffers live on (= the context's device at creation)
   int comb_m = 0;          // comb pilots 1 : comb : ... -> Nfft / comb, else 0
   int comb_lg_up = -1;     // comb pilots 1 : comb : ... with (Nfft/comb) dividing 512 -> log2(512 / (Nfft/comb))
   void *d_prole, *d_drole, *d_pilots, *d_sct, *d_gram, *d_pc0;
@@ -34,6 +35,15 @@ struct ofdm_rx_plan {
   size_t ws_t4_bytes = 0;
   void* d_p2_sop = nullptr; // ofdm_task5_part2_tile: spline operator of interpolate.m [n_carrier x np], double
 };
+
+// every entry that takes a plan: the context must still be on the plan's device
+#define OFDM_PLAN_DEVICE(pl)                                                                                      \
+  do {                                                                                                           \
+    if ((pl)->device != ::ofdm::ctx().device) {                                                                  \
+      ::ofdm::set_error("RX plan belongs to device %d, the context is on device %d", (pl)->device, ::ofdm::ctx().device); \
+      return OFDM_ERR_STATE;                                                                                     \
+    }                                                                                                            \
+  } while (0)
 
 // view of a plan for the fast / split stages
 inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {

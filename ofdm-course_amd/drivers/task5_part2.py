@@ -79,7 +79,10 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
         Tx = np.asarray(lib.OFDM_modulator(X, T_Guard)).ravel(order="F")            # :130-132
         Tx_noised, _ = lib.Noise(SNR_dB, Tx, seed=seed, stream=kk)                  # :134 (noise BEFORE the channel)
         mine = [jj for jj in range(monteCarloRuns) if (kk * monteCarloRuns + jj) % world == rank]
-        use_tile = (batched if batched is not None else hasattr(lib, "task5_part2_tile")) and len(mine) > 0
+        # the tile needs a payload (the 100 % pilot rule of :67-75 leaves none), two pilots and a dictionary whose batch-OMP state
+        # fits the LDS (K <= 2048 atoms); every other scenario runs call by call on the same library
+        tile_ok = len(dataCarriers) > 0 and len(pilotCarriers) >= 2 and K <= 2048
+        use_tile = (batched if batched is not None else hasattr(lib, "task5_part2_tile")) and len(mine) > 0 and tile_ok
         if use_tile:
             # :148-304 for all of this rank's realisations of scenario kk in one call
             from .. import frames as fr

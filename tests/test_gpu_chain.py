@@ -346,3 +346,24 @@ def test_chain_plans_interleaved_and_growing_batches(ofdm, oracle):
         pb.set_mmse(None)
     out0 = ofdm.rx_chain_task5(pa, np.asarray(data_a["rx"])[:, :0])
     assert np.asarray(out0["bits"]).shape[0] == 0
+
+
+def test_context_is_pinned_to_its_device_while_plans_live(ofdm):
+    """One device per process: ofdm_init for another device must not tear the context down under live RX
+    plans -- it used to free the twiddle cache and re-aim their launches.  With one visible GPU the other
+    device id is out of range (argument error); either way the plan keeps working and the context stays on device 0."""
+    from ofdm_course_amd import frames as fr, _lib
+    cfg = fr.config_small()
+    plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
+    lib = _lib.load()
+    import torch
+    n = torch.cuda.device_count()
+    rc = lib.ofdm_init(1)
+    assert rc < 0
+    msg = lib.ofdm_last_error_string().decode()
+    assert ("one device per process" in msg) if n > 1 else ("out of range" in msg), msg
+    data = fr.make_frames(cfg, ofdm, 2, seed=3, precision="fp32")
+    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"])
+    assert np.asarray(out["errors"]).shape == (2,)
+    plan.close()
+    assert lib.ofdm_init(0) == 0
