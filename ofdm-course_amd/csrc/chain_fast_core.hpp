@@ -455,9 +455,13 @@ inline int resident_blocks_per_cu(const void* kern, int threads, size_t dyn) {
 // BA = bits per axis of a square QAM (2, 3, 4: the slicer thresholds become compile-time-indexed scalars;
 // with a run-time switch every variant's constants stay live and the kernel spills ~80 SGPRs to VGPR lanes),
 // BA = 0: any constellation through the generic decision function.
-template <typename T, int BA>
+// Throughput mode (fp32 chains, EXACT = false): the arithmetic level rank of demap_square_arith -- decisions can differ from
+// the threshold count only within a few ulp of a threshold (SURVEY 8c allows 1e-4), the centre threshold is compared exactly.
+// Parity mode (fp64) and EXACT = true: every threshold counted.
+template <typename T, int BA, bool EXACT = false>
 __device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
   if constexpr (BA == 0) return demap_decide(tab, z);
+  else if constexpr (std::is_same<T, float>::value && BA >= 2 && !EXACT) return demap_square_arith<BA>(tab, z);
   else return demap_square<T, BA>(tab, z);
 }
 

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
               const cx<T> xs = xv[v][u];
               const cx<T> ye = xs * geq[k0 + 256 * u];
               int code;
-              if constexpr (BA >= 2) code = demap_square_lut<T, BA>(tab, sh_lut, ye);
-              else code = slice_symbol<T, BA>(tab, ye);
+              if constexpr (BA >= 2 && sizeof(T) == 8) code = demap_square_lut<T, BA>(tab, sh_lut, ye);   // parity mode: exact, 9 ops / axis
+              else code = slice_symbol<T, BA>(tab, ye);                                                  // fp32: arithmetic rank
               codes[(s0 + v) * nd + dv[u]] = (uint8_t)code;
             }
       }

@@ -63,13 +63,15 @@ __device__ __forceinline__ cx<float> w32(int m) {
 
 // LUT: level rank by arithmetic guess + the two neighbouring thresholds from LDS (demap_square_lut) instead of counting all
 // 2^BA - 1 thresholds
-template <int BA, bool LUT>
+// SL = 0: count all 2^BA - 1 thresholds (demap_square); 1: LUT; 2: arithmetic rank around the exactly compared centre
+template <int BA, int SL>
 __device__ __forceinline__ int slice_wave(const DemapTable<float>& tab, const float* lut, cx<float> z) {
-  if constexpr (LUT && BA >= 2) return demap_square_lut<float, BA>(tab, lut, z);
-  else return slice_symbol<float, BA>(tab, z);
+  if constexpr (SL == 1 && BA >= 2) return demap_square_lut<float, BA>(tab, lut, z);
+  else if constexpr (SL == 2 && BA >= 2) return demap_square_arith<BA>(tab, z);
+  else return slice_symbol<float, BA, true>(tab, z);
 }
 
-template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, bool LUT = false>
+template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, int LUT = 2>
 __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_kernel(FastParams<float> P, WaveLayout lay,
                                                                   const cx<float>* __restrict__ rx, int64_t n_frames,
                                                                   uint32_t* __restrict__ bits_out,
@@ -345,11 +347,12 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
     return OFDM_OK;
   };
   const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
-  const bool nowb = getenv("OFDM_WAVE_NO_WBUF") != nullptr, uselut = getenv("OFDM_WAVE_LUT") != nullptr;   // LUT slicer: measured 3 % slower at 64-QAM here (7 thresholds per axis)
+  const bool nowb = getenv("OFDM_WAVE_NO_WBUF") != nullptr, uselut = getenv("OFDM_WAVE_LUT") != nullptr, exact = getenv("OFDM_WAVE_EXACT_SLICER") != nullptr;   // LUT slicer: measured 3 % slower at 64-QAM here (7 thresholds per axis)
 #define WAVE_CASE(BAV, HX)                                                                \
   if (wpb == 8) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 8>));                     \
-  else if (nowb) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, false>));          \
-  else if (uselut) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, true>));   \
+  else if (nowb) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, false, 0>));          \
+  else if (uselut) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 1>));   \
+  else if (exact) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 0>));   \
   else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4>))
   if (mmse) {
     switch (ba) {

@@ -55,10 +55,13 @@ def config_M():
 
 
 def config_C5(seed=5):
-    """Nfft=8192, 256-QAM, sparse 32-tap channel (seeded), OMP(32)."""
+    """Nfft=8192, 256-QAM, sparse 32-tap channel (seeded), OMP(32).  The 32 delays are drawn below K = ceil(N_carrier/comb)
+    = 512 samples (T5/Main_model_Task_5.m:184: the dictionary the estimator is given has K columns, so a longer echo is
+    not representable and only sets an error floor -- round 1 drew them below T_guard = 1024 and its BER(SNR) sweep
+    flattened at 0.11); still well inside the guard interval."""
     rng = np.random.default_rng(seed)
     tg = 8192 // 8
-    d = np.sort(rng.choice(tg, 32, replace=False))
+    d = np.sort(rng.choice(512, 32, replace=False))
     a = (rng.standard_normal(32) + 1j * rng.standard_normal(32)) / np.sqrt(2) * np.exp(-d / (tg / 4))
     taps = np.stack([d.astype(complex), a], axis=1)
     return FrameConfig("C5", 8192, 2048, 4, "256QAM", taps=taps, dominant_taps=32)

@@ -25,10 +25,16 @@ ofdm.init(0)
 HBM = 8000.0
 
 
-def timed(fn, reps=5, warm=2):
+def timed(fn, reps=5, warm=2, settle_s=0.3):
+    """ms per call over `reps` calls, after `warm` calls and at least `settle_s` seconds of back-to-back calls: a fresh process
+    reaches its steady clocks only after ~0.2 s of launches (short cold runs read 10-25 % slow)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):

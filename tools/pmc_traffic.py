@@ -8,7 +8,7 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20480      # bench.py defaul
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(d + "/tcc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(fn)):
-        for key in ("rx_pilot_omp_kernel", "rx_pilot_kernel", "omp_batch_kernel", "rx_symbols_kernel"):
+        for key in ("rx_pilot_omp_kernel", "rx_pilot_kernel", "omp_batch_kernel", "rx_symbols_wave_kernel", "rx_symbols_kernel"):
             if key + "<" in r["Kernel_Name"]:
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out, tot = {}, 0.0
