@@ -218,14 +218,17 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
 #pragma unroll
       for (int j0 = 0; j0 < 4; ++j0) {
         if (WBUF && j0 == 3) {
+          // transform the look-ahead registers where they are, hand the results to the (free) slots j = 4 c + 3, THEN refill
+          dft8<T, false>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[4 * c + 3] = w[c];
           if constexpr (ABL != 1) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) w[c] = nt_load(nsrc + 64 * (4 * c + 3));
           }
+        } else {
+          dft8<T, false>(v[j0], v[j0 + 4], v[j0 + 8], v[j0 + 12], v[j0 + 16], v[j0 + 20], v[j0 + 24], v[j0 + 28]);
         }
-        dft8<T, false>(v[j0], v[j0 + 4], v[j0 + 8], v[j0 + 12], v[j0 + 16], v[j0 + 20], v[j0 + 24], v[j0 + 28]);
         if (j0 > 0) {
 #pragma unroll
           for (int ka = 1; ka < 8; ++ka) v[j0 + 4 * ka] = v[j0 + 4 * ka] * w32(j0 * ka);
