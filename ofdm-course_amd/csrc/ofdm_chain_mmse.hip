@@ -91,9 +91,10 @@ int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t*
 // ---------------------------------------------------------------------------------------------
 // H[f][m] = sum_p W[m][p] Y[f][p]
 // fp32: real GEMM  C[M x 2F] = [Wr | Wi] * B,  B(p,re;2f) = Yr, B(p,im;2f) = -Yi, B(p,re;2f+1) = Yi, B(p,im;2f+1) = Yr.
-// One wavefront = 16 rows x 32 frames (four 16x16 tiles: 8 frames each, columns 2f / 2f+1 = Re / Im).  One k-step =
-// 4 pilots = 8 MFMAs; both operands come straight from L2 (W^T: 16 consecutive rows per pilot; Y: 32-byte runs),
-// the next k-step's operands are requested before this step's MFMAs issue.  No LDS: occupancy hides the latency.
+// One wavefront = 32 rows x 64 frames (2 x 8 tiles of 16x16: 8 frames each, columns 2f / 2f+1 = Re / Im).  One k-step =
+// 8 pilots = 64 MFMAs fed by 4 + 8 loads (W^T: 16 consecutive rows per pilot; Y: one 16-byte load = 2 pilots per frame
+// group), both straight from L2; the next k-step's operands are requested before this step's MFMAs issue.  The round-1
+// tile (16 x 32, 5 loads per 8 MFMAs) was bound by the texture path, not by the matrix pipe (38.6 % MFMA busy).
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -102,51 +103,78 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
                                                               int64_t n_frames) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i16 = lane & 15, q = lane >> 4, fsub = i16 >> 1, cim = i16 & 1;
-  const int m0 = (blockIdx.y * 4 + wave) * 16;
+  const int m0 = (blockIdx.y * 4 + wave) * 32;
   if (m0 >= m_pad) return;                                   // wavefront-uniform
-  const int64_t f0 = (int64_t)blockIdx.x * 32;
-  f32x4 acc[4];
+  const bool two = m0 + 16 < m_pad;                          // wavefront-uniform: second carrier tile exists
+  const int64_t f0 = (int64_t)blockIdx.x * 64;
+  f32x4 acc[2][8];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0, 0, 0, 0};
-  const cx<float>* ap = wt + m0 + i16;                        // + p * m_pad
-  const cx<float>* yp[4];
-  bool yv[4];
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 8; ++g) acc[t][g] = f32x4{0, 0, 0, 0};
+  const cx<float>* ap[2] = {wt + m0 + i16, wt + (two ? m0 + 16 : m0) + i16};     // + p * m_pad
+  const float4* yp[8];
+  bool yv[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
     const int64_t f = f0 + 8 * g + fsub;
     yv[g] = f < n_frames;
-    yp[g] = y + (yv[g] ? f : 0) * np;
+    yp[g] = reinterpret_cast<const float4*>(y + (yv[g] ? f : 0) * np + 2 * q);   // 16-byte aligned: np is even
   }
-  cx<float> a = ap[(size_t)q * m_pad], b[4];
+  // one k-step = 8 pilots: the lane holds pilots p0 + 2q and p0 + 2q + 1 (one 16-byte load per frame group), the first MFMA
+  // round contracts the even ones, the second the odd ones
+  cx<float> a[2][2];
+  float4 b[8];
+  auto fetch = [&](int p0, cx<float> (&aa)[2][2], float4 (&bb)[8]) {
+    const int pa = p0 + 2 * q;
+    const bool ok = pa < np;                                 // np % 4 == 0: the pair is valid or not as a whole
+    const int pc = ok ? pa : 0;                              // loads are unconditional (clamped); the tail is zeroed in B
+    const size_t row = (size_t)pc * m_pad;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) b[g] = yv[g] ? yp[g][q] : mk<float>(0, 0);
-  for (int p0 = 0; p0 < np; p0 += 4) {
-    const int pn = p0 + 4 < np ? p0 + 4 : p0;
-    const cx<float> an = ap[(size_t)(pn + q) * m_pad];
-    cx<float> bn[4];
+    for (int t = 0; t < 2; ++t) { aa[t][0] = ap[t][row]; aa[t][1] = ap[t][row + m_pad]; }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bn[g] = yv[g] ? yp[g][pn + q] : mk<float>(0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float b_re = cim ? b[g].y : b[g].x;               // multiplies Re(W)
-      const float b_im = cim ? b[g].x : -b[g].y;              // multiplies Im(W)
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b_re, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b_im, acc[g], 0, 0, 0);
+    for (int g = 0; g < 8; ++g) {
+      const float4 v = yp[g][(pc - 2 * q) >> 1];             // frames past the end read frame 0 and are never stored
+      bb[g] = ok ? v : float4{0, 0, 0, 0};
     }
-    a = an;
+  };
+  fetch(0, a, b);
+  for (int p0 = 0; p0 < np; p0 += 8) {
+    cx<float> an[2][2];
+    float4 bn[8];
+    fetch(p0 + 8 < np ? p0 + 8 : p0, an, bn);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b[g] = bn[g];
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float yr = h ? b[g].z : b[g].x, yi = h ? b[g].w : b[g].y;
+        const float b_re = cim ? yi : yr;                       // multiplies Re(W)
+        const float b_im = cim ? yr : -yi;                      // multiplies Im(W)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][h].x, b_re, acc[t][g], 0, 0, 0);
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][h].y, b_im, acc[t][g], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { a[t][0] = an[t][0]; a[t][1] = an[t][1]; }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) b[g] = bn[g];
   }
   // C: lane holds rows 4*(lane>>4)+r of column lane&15
   float* ho = reinterpret_cast<float*>(hout);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int64_t f = f0 + 8 * g + fsub;
-    if (f < n_frames) {
+  for (int t = 0; t < 2; ++t) {
+    if (t == 1 && !two) break;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * q + r;
-        if (m < n_carrier) ho[2 * (f * n_carrier + m) + cim] = acc[g][r];
+    for (int g = 0; g < 8; ++g) {
+      const int64_t f = f0 + 8 * g + fsub;
+      if (f < n_frames) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 16 * t + 4 * q + r;
+          if (m < n_carrier) ho[2 * (f * n_carrier + m) + cim] = acc[t][g][r];
+        }
       }
     }
   }
@@ -177,7 +205,7 @@ int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad,
   hipStream_t st = ctx().stream;
   if constexpr (std::is_same<T, float>::value) {
     if (np % 4 == 0 && m_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA")) {
-      const dim3 grid((unsigned)((n_frames + 31) / 32), (unsigned)((m_pad / 16 + 3) / 4));
+      const dim3 grid((unsigned)((n_frames + 63) / 64), (unsigned)(((m_pad + 31) / 32 + 3) / 4));
       hipLaunchKernelGGL(mmse_apply_mfma_kernel, grid, dim3(256), 0, st, (const cx<float>*)wt, (const cx<float>*)y,
                          (cx<float>*)hout, np, m_pad, n_carrier, n_frames);
       return check_launch("mmse_apply_mfma_kernel");
