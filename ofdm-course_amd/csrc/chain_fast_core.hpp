@@ -281,9 +281,12 @@ __device__ __forceinline__ void omp_frame_reg(const FastParams<T>& P, const cx<T
       for (int qq = 0; qq < it; ++qq) {
         const int d = pk[qq] - k;
         const cx<T> gv = gl[d >= 0 ? d : -d];
-        c = c - (d >= 0 ? gv : conj(gv)) * xr[qq];
+        if constexpr (sizeof(T) == 4) cmsub(c, mk<T>(gv.x, d >= 0 ? gv.y : -gv.y), xr[qq]);      // four FMAs (fp32 mode)
+        else c = c - (d >= 0 ? gv : conj(gv)) * xr[qq];
       }
-      const float sc = (float)((double)c.x * c.x + (double)c.y * c.y);
+      float sc;
+      if constexpr (sizeof(T) == 4) sc = c.x * c.x + c.y * c.y;       // fp32 mode: near-ties fall under the 1e-4 rule
+      else sc = (float)((double)c.x * c.x + (double)c.y * c.y);
       if (sc > bs) { bs = sc; bi = k; }          // ascending k inside a lane: strict > keeps the first
     }
     // first maximum over the group: the largest score, then the smallest index among the lanes that hold it
@@ -312,7 +315,10 @@ __device__ __forceinline__ void omp_frame_reg(const FastParams<T>& P, const cx<T
           const int d = pk[jq] - kp;
           cx<T> sgm = d >= 0 ? gl[d] : conj(gl[-d]);
 #pragma unroll
-          for (int k2 = 0; k2 < jq; ++k2) sgm = sgm - mulc(Lr[it * (it + 1) / 2 + k2], Lr[jq * (jq + 1) / 2 + k2]);
+          for (int k2 = 0; k2 < jq; ++k2) {
+            if constexpr (sizeof(T) == 4) cmsubc(sgm, Lr[it * (it + 1) / 2 + k2], Lr[jq * (jq + 1) / 2 + k2]);
+            else sgm = sgm - mulc(Lr[it * (it + 1) / 2 + k2], Lr[jq * (jq + 1) / 2 + k2]);
+          }
           const cx<T> l = sgm * Ld[jq];
           Lr[it * (it + 1) / 2 + jq] = l;
           dd -= norm2(l);
@@ -322,7 +328,10 @@ __device__ __forceinline__ void omp_frame_reg(const FastParams<T>& P, const cx<T
         // forward substitution (only the new entry changes): b_it = a_it^H y = c0[kp]
         cx<T> sz = cf[kp];
 #pragma unroll
-        for (int k2 = 0; k2 < it; ++k2) sz = sz - Lr[it * (it + 1) / 2 + k2] * zr[k2];
+        for (int k2 = 0; k2 < it; ++k2) {
+          if constexpr (sizeof(T) == 4) cmsub(sz, Lr[it * (it + 1) / 2 + k2], zr[k2]);
+          else sz = sz - Lr[it * (it + 1) / 2 + k2] * zr[k2];
+        }
         const cx<T> zn = sz * inv_lnn;
         zr[it] = zn;
         // back substitution L^H x = z
@@ -330,7 +339,10 @@ __device__ __forceinline__ void omp_frame_reg(const FastParams<T>& P, const cx<T
         for (int r = it; r >= 0; --r) {
           cx<T> acc = zr[r];
 #pragma unroll
-          for (int k2 = r + 1; k2 <= it; ++k2) acc = acc - mulc(xr[k2], Lr[k2 * (k2 + 1) / 2 + r]);
+          for (int k2 = r + 1; k2 <= it; ++k2) {
+            if constexpr (sizeof(T) == 4) cmsubc(acc, xr[k2], Lr[k2 * (k2 + 1) / 2 + r]);
+            else acc = acc - mulc(xr[k2], Lr[k2 * (k2 + 1) / 2 + r]);
+          }
           xr[r] = acc * Ld[r];
         }
         // ||r_n||^2 = ||r_{n-1}||^2 - |z_n|^2 ; stop when ||r_n - r_{n-1}|| / ||r_{n-1}|| < 1e-2 (:20)

@@ -75,28 +75,24 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
     } else {
       // H(k) = sum_q x_q W^(idx_q k) for the thread's carriers k = base + gid + 256 u.  A table lookup per (carrier, tap)
       // is a 64-address gather (stride idx_q) and made this stage gather-bound; instead ONE lookup per tap gives
-      // W^(idx_q (base + gid)) and the wavefront-uniform step W^(256 idx_q) carries it to the next carrier in double.
+      // x_q W^(idx_q (base + gid)) and the eight wavefront-uniform factors W^(256 u idx_q) come through the scalar cache:
+      // four FMAs per (carrier, tap), exact table values at both ends (an eight-step recurrence cost eight).
       for (int base = 0; base < nc; base += 8 * 256) {
-        // (sums and the eight-step twiddle recurrence in the data precision: exact table values at both ends of every
-        //  recurrence, 32 terms -- error ~1e-6 of |H| in fp32 mode, where H itself is delivered in fp32)
         T hr[8], hi[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) hr[u] = hi[u] = 0;
         for (int q = 0; q < taps; ++q) {
-          const int idx = sh_tidx[q];
+          const int idx = __builtin_amdgcn_readfirstlane(sh_tidx[q]);
           if (idx < 0) continue;                                       // wavefront-uniform
           const cx<T> x = mk<T>((T)sh_tx[q].x, (T)sh_tx[q].y);
-          const cx<T> w0 = P.tw[(int)(((int64_t)idx * (base + gid)) & (nfft - 1))];
-          const cx<T> st = P.tw[(int)(((int64_t)idx * 256) & (nfft - 1))];
-          T wr = w0.x, wi = w0.y;
-          const T sr = st.x, si = st.y;
+          const cx<T> xw = x * P.tw[(int)(((int64_t)idx * (base + gid)) & (nfft - 1))];
+          cx<T> st[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) st[u] = uniform_load(P.tw + ((idx * 256 * u) & (nfft - 1)));
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            hr[u] += x.x * wr - x.y * wi;
-            hi[u] += x.x * wi + x.y * wr;
-            const T nr = wr * sr - wi * si;
-            wi = wr * si + wi * sr;
-            wr = nr;
+            hr[u] = fma(xw.x, st[u].x, hr[u]); hr[u] = fma(-xw.y, st[u].y, hr[u]);
+            hi[u] = fma(xw.x, st[u].y, hi[u]); hi[u] = fma(xw.y, st[u].x, hi[u]);
           }
         }
 #pragma unroll

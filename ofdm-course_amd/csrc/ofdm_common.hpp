@@ -45,6 +45,37 @@ template <typename T> __host__ __device__ inline cx<T> cdiv(cx<T> a, cx<T> b) {
   T d = T(1) / (b.x * b.x + b.y * b.y);
   return mk<T>((a.x * b.x + a.y * b.y) * d, (a.y * b.x - a.x * b.y) * d);
 }
+// c -= g * x and c += a * b as four fused multiply-adds each (the operator forms cost six: product, then add)
+template <typename T>
+__device__ __forceinline__ void cmsub(cx<T>& c, cx<T> g, cx<T> x) {
+  c.x = fma(-g.x, x.x, c.x); c.x = fma(g.y, x.y, c.x);
+  c.y = fma(-g.x, x.y, c.y); c.y = fma(-g.y, x.x, c.y);
+}
+template <typename T>
+__device__ __forceinline__ void cmadd(cx<T>& c, cx<T> a, cx<T> b) {
+  c.x = fma(a.x, b.x, c.x); c.x = fma(-a.y, b.y, c.x);
+  c.y = fma(a.x, b.y, c.y); c.y = fma(a.y, b.x, c.y);
+}
+template <typename T>
+__device__ __forceinline__ void cmsubc(cx<T>& c, cx<T> a, cx<T> b) {      // c -= a * conj(b)
+  c.x = fma(-a.x, b.x, c.x); c.x = fma(-a.y, b.y, c.x);
+  c.y = fma(-a.y, b.x, c.y); c.y = fma(a.x, b.y, c.y);
+}
+template <typename T>
+__device__ __forceinline__ void cmaddc(cx<T>& c, cx<T> a, cx<T> b) {      // c += a * conj(b)
+  c.x = fma(a.x, b.x, c.x); c.x = fma(a.y, b.y, c.x);
+  c.y = fma(a.y, b.x, c.y); c.y = fma(-a.x, b.y, c.y);
+}
+
+// Load through the scalar cache: for a wavefront-uniform address into memory that no kernel of the launch writes (the
+// twiddle tables).  hipcc only selects s_load for the constant address space, hence the cast.
+template <typename T>
+__device__ __forceinline__ cx<T> uniform_load(const cx<T>* p) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(4))) v2* cptr;
+  const v2 q = *(cptr)(uintptr_t)p;
+  return mk<T>(q.x, q.y);
+}
 // multiply by -i (forward) / +i (inverse)
 template <typename T, bool INV> __host__ __device__ inline cx<T> mul_mi(cx<T> a) {
   return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);

@@ -53,6 +53,10 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
   int n = 0;
   double rho = ynorm;
   bool active = live;                            // wave-uniform
+  if constexpr (sizeof(T) == 4) {
+    for (int i = lane; i < taps * RS; i += 64) Rm[i] = mk<T>(0, 0);
+    wave_sync();
+  }
   for (int it = 0; it < taps && active; ++it) {
     const int ns = __builtin_amdgcn_readfirstlane(n);        // picks made so far, in a scalar register: uniform loops
     // ---- residual correlation c = c0 - G(:, index) x and its first arg-max (OMP_estimate.m:7,:14)
@@ -78,14 +82,18 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
 #pragma unroll
           for (int u = 0; u < 8; ++u) gb[u] = gk[pn + 64 * (7 - u)];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) c[u] = c[u] - ga[u] * xa;
+          for (int u = 0; u < 8; ++u) {
+            if constexpr (sizeof(T) == 4) cmsub(c[u], ga[u], xa); else c[u] = c[u] - ga[u] * xa;
+          }
           if (two) {
             const cx<T> xb = lane_bcast(xq, q + 1);
             const int p2 = __builtin_amdgcn_readlane(pk, q + 2 < ns ? q + 2 : q + 1);
 #pragma unroll
             for (int u = 0; u < 8; ++u) ga[u] = gk[p2 + 64 * (7 - u)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = c[u] - gb[u] * xb;
+            for (int u = 0; u < 8; ++u) {
+              if constexpr (sizeof(T) == 4) cmsub(c[u], gb[u], xb); else c[u] = c[u] - gb[u] * xb;
+            }
           }
         }
       }
@@ -93,7 +101,9 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
       for (int u = 0; u < 8; ++u) {
         const int k = kb + 64 * u;
         if (k < K) {
-          const float sc = (float)((double)c[u].x * c[u].x + (double)c[u].y * c[u].y);
+          float sc;
+          if constexpr (sizeof(T) == 4) sc = c[u].x * c[u].x + c[u].y * c[u].y;     // fp32 mode: near-ties fall under the 1e-4 rule
+          else sc = (float)((double)c[u].x * c[u].x + (double)c[u].y * c[u].y);
           if (sc > bs) { bs = sc; bi = k; }      // ascending k inside a lane: strict > keeps the first
         }
       }
@@ -115,10 +125,14 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
     cx<T> g = mk<T>(0, 0);
     if (lane < n) g = g2[KP + pk - kp];
     cx<T> l = mk<T>(0, 0);
-    const cx<T>* Rrow = Rm + lane * RS;
+    // fp32: R's upper triangle holds zeros (cleared per frame below), so the sums run unconditionally over k < n; lanes
+    // past the picks read a clamped row / column and their results are never used
+    const int lc = lane < taps ? lane : taps - 1;
+    const cx<T>* Rrow = Rm + (sizeof(T) == 4 ? lc : lane) * RS;
     for (int k = 0; k < ns; ++k) {
       const cx<T> gq = lane_bcast(g, k);
-      if (k <= lane && lane < n) l = l + mulc(gq, Rrow[k]);
+      if constexpr (sizeof(T) == 4) cmaddc(l, gq, Rrow[k]);
+      else if (k <= lane && lane < n) l = l + mulc(gq, Rrow[k]);
     }
     const T nrm = wave_sum(lane < n ? norm2(l) : T(0), lane);
     const cx<T> lzp = l * zq;                    // zq = 0 in lanes >= n
@@ -129,7 +143,8 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
     cx<T> r = mk<T>(0, 0);
     for (int k = 0; k < ns; ++k) {
       const cx<T> lq = lane_bcast(l, k);
-      if (k >= lane && lane < n) r = r + lq * Rm[k * RS + lane];
+      if constexpr (sizeof(T) == 4) cmadd(r, lq, Rm[k * RS + lc]);
+      else if (k >= lane && lane < n) r = r + lq * Rm[k * RS + lane];
     }
     r = r * (-inv);
     if (lane < n) {
