@@ -19,10 +19,11 @@ step bench2
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 200 --warmup 20 --frames 8192 > $out/bench_gpus2_gloo_rehearsal.json 2> $out/bench2.err || echo "2-rank rehearsal failed"
 step clock
 bash tools/clock_probe.sh $out/clock > $out/clock_probe.txt 2>&1
+export C5_WARM_S=0.5
 step c5
 timeout -k 10 300 python tools/c5_run.py 2048 20 > $out/c5.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5_stats -- python tools/c5_run.py 2048 20 > /dev/null 2>&1 && cp $out/c5_stats/*/*kernel_stats.csv $out/c5_kernel_stats.csv
-bash tools/pmc_cmd.sh $out/c5_pmc python tools/c5_run.py 2048 5 > $out/c5_pmc_summary.txt 2>&1
+C5_WARM_S=0.02 bash tools/pmc_cmd.sh $out/c5_pmc python tools/c5_run.py 2048 5 > $out/c5_pmc_summary.txt 2>&1
 timeout -k 10 300 python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 2 --frames-per-tile 64 --json $out/sweep_c5.json > /dev/null 2>&1
 step c3
 timeout -k 10 300 python tools/c3_run.py 1024 20 > $out/c3.txt 2>&1
@@ -36,5 +37,8 @@ timeout -k 10 600 python tools/bench_configs.py > $out/secondary_configs.jsonl 2
 bash tools/pmc_cmd.sh $out/c4_pmc python tools/bench_configs.py C4 > $out/c4_pmc_summary.txt 2>&1
 step ubench
 tools/ubench/hbm_read > $out/hbm_read.txt 2>&1
+# raw per-dispatch tables stay on the box: only the summaries travel (gpurun merges at most 64 MiB)
+rm -rf $out/stats $out/c5_stats $out/c3_stats $out/pmc/*/ $out/c5_pmc/*/ $out/part2_pmc/*/ $out/c4_pmc/*/ $out/clock
+du -sh $out >> $out/progress.txt
 step done
 head -c 400 $out/final_bench.json; echo
