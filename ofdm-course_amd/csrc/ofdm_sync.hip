@@ -31,12 +31,16 @@ constexpr int ACF_THREADS = 256;
 constexpr int ACF_MAXW = 1024;                       // WidthWindow limit (T_guard <= 1024 <-> Nfft <= 8192)
 constexpr int ACF_ELEMS = ACF_TILE + ACF_MAXW;       // prefix entries 0..ACF_ELEMS
 
-struct acf4 { double pr, pi, e1, e2; };
+// accumulation type A: double in parity mode; float in fp32 mode (tile-local prefixes of <= 2048 terms: the window sums
+// keep ~1e-6 relative accuracy, the fp32 tolerance of rho is 1e-4) -- 16-byte table entries, 20 KB per workgroup instead of
+// 64 KB (seven resident workgroups per CU instead of two) and a float square root / reciprocal per output
+template <typename A> struct acf4 { A pr, pi, e1, e2; };
 
-__device__ __forceinline__ acf4 acf_add(acf4 a, acf4 b) { return acf4{a.pr + b.pr, a.pi + b.pi, a.e1 + b.e1, a.e2 + b.e2}; }
-__device__ __forceinline__ acf4 acf_shfl_up(acf4 v, int d) {
-  return acf4{__shfl_up(v.pr, d, 64), __shfl_up(v.pi, d, 64), __shfl_up(v.e1, d, 64), __shfl_up(v.e2, d, 64)};
+template <typename A> __device__ __forceinline__ acf4<A> acf_add(acf4<A> a, acf4<A> b) { return acf4<A>{a.pr + b.pr, a.pi + b.pi, a.e1 + b.e1, a.e2 + b.e2}; }
+template <typename A> __device__ __forceinline__ acf4<A> acf_shfl_up(acf4<A> v, int d) {
+  return acf4<A>{__shfl_up(v.pr, d, 64), __shfl_up(v.pi, d, 64), __shfl_up(v.e1, d, 64), __shfl_up(v.e2, d, 64)};
 }
+template <typename T> inline size_t acf_lds_bytes(int W) { return sizeof(acf4<T>) * (size_t)(ACF_TILE + W + 1); }
 
 template <typename T>
 __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
@@ -46,8 +50,11 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out).  With a frame list
   // (the frames a prefix of rho did not settle) grid.y strides over the list instead: a launch over an empty list costs
   // a few hundred idle workgroups, not one per (tile, frame) -- that alone was 60 us per 1024 frames.
-  __shared__ acf4 S[ACF_ELEMS + 1];                  // exclusive prefix: S[i] = sum_{m<i}
-  __shared__ acf4 wtot[ACF_THREADS / 64];
+  using A = T;
+  using acc = acf4<A>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char acf_smem[];
+  acc* const S = (acc*)acf_smem;                     // [ACF_TILE + W + 1] exclusive prefix: S[i] = sum_{m<i}
+  __shared__ acc wtot[ACF_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const cx<T>* const x_all = x;
   cx<T>* const rho_all = rho;
@@ -64,32 +71,32 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   constexpr int EMAX = ACF_ELEMS / ACF_THREADS;                   // 8
   const int E = (m_cnt + ACF_THREADS - 1) / ACF_THREADS;          // <= EMAX
   const int lo_i = tid * E;
-  acf4 pre[EMAX];
-  acf4 run{0, 0, 0, 0};
+  acc pre[EMAX];
+  acc run{0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < EMAX; ++j) {
     const int i = lo_i + j;
     if (j < E && i < m_cnt) {
       const int64_t m = n0 + i;                      // m + nfft < len is guaranteed by n_out
       const cx<T> a = x[m], b = x[m + nfft];
-      const double ar = a.x, ai = a.y, br = b.x, bi = b.y;
-      run = acf_add(run, acf4{ar * br + ai * bi,     // a * conj(b)
-                              ai * br - ar * bi, ar * ar + ai * ai, br * br + bi * bi});
+      const A ar = a.x, ai = a.y, br = b.x, bi = b.y;
+      run = acf_add(run, acc{ar * br + ai * bi,      // a * conj(b)
+                             ai * br - ar * bi, ar * ar + ai * ai, br * br + bi * bi});
     }
     pre[j] = run;
   }
   // (2) ... one exclusive scan of the 256 run totals (wave shuffle scan + carry of the earlier wavefronts) ...
-  acf4 v = run;
+  acc v = run;
   for (int d = 1; d < 64; d <<= 1) {
-    acf4 u = acf_shfl_up(v, d);
+    acc u = acf_shfl_up(v, d);
     if (lane >= d) v = acf_add(v, u);
   }
   if (lane == 63) wtot[wid] = v;
-  if (tid == 0) S[0] = acf4{0, 0, 0, 0};
+  if (tid == 0) S[0] = acc{0, 0, 0, 0};
   __syncthreads();
-  acf4 off{0, 0, 0, 0};
+  acc off{0, 0, 0, 0};
   for (int w = 0; w < wid; ++w) off = acf_add(off, wtot[w]);
-  off = acf_add(off, acf4{v.pr - run.pr, v.pi - run.pi, v.e1 - run.e1, v.e2 - run.e2});
+  off = acf_add(off, acc{v.pr - run.pr, v.pi - run.pi, v.e1 - run.e1, v.e2 - run.e2});
   // (3) ... and the prefix table is written once: S[i+1] = sum_{m <= i}
 #pragma unroll
   for (int j = 0; j < EMAX; ++j) {
@@ -98,13 +105,29 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   }
   __syncthreads();
   for (int i = tid; i < n_here; i += ACF_THREADS) {
-    const acf4 hi = S[i + W], lo = S[i];
-    const double pr = hi.pr - lo.pr, pi = hi.pi - lo.pi, e1 = hi.e1 - lo.e1, e2 = hi.e2 - lo.e2;
-    const double den = sqrt(e1 * e2);                // AutoCorrFunction.m:6
-    rho[n0 + i] = mk<T>((T)(pr / den), (T)(pi / den));
+    const acc hi = S[i + W], lo = S[i];
+    const A pr = hi.pr - lo.pr, pi = hi.pi - lo.pi, e1 = hi.e1 - lo.e1, e2 = hi.e2 - lo.e2;
+    const A den = sqrt(e1 * e2);                     // AutoCorrFunction.m:6
+    if constexpr (sizeof(A) == 4) {
+      const A inv = A(1) / den;
+      rho[n0 + i] = mk<T>(pr * inv, pi * inv);
+    } else {
+      rho[n0 + i] = mk<T>((T)(pr / den), (T)(pi / den));
+    }
   }
   __syncthreads();                                   // S / wtot are reused by the next listed frame
   }
+}
+
+// dynamic LDS beyond 64 KB (double table at WidthWindow = 1024) has to be allowed once per kernel
+template <typename T>
+static int acf_prepare() {
+  static bool done = false;
+  if (!done) {
+    OFDM_HIP(hipFuncSetAttribute((const void*)acf_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acf_lds_bytes<T>(ACF_MAXW)));
+    done = true;
+  }
+  return OFDM_OK;
 }
 
 // frames whose plateau search did not succeed on the prefix of rho (res[2 f + 1] == 0), in any order
@@ -734,6 +757,13 @@ __global__ __launch_bounds__(128) void t4_apply_operator_kernel(const T* __restr
     if (f0 + f < n_frames) hout[(f0 + f) * n_out + m] = mk<T>((T)ar[f], (T)ai[f]);
 }
 
+__global__ void t4_init_kernel(int32_t* __restrict__ stat, int64_t* __restrict__ tg, double* __restrict__ fo, int32_t* __restrict__ ifo,
+                               int32_t* __restrict__ fcount, int64_t n_frames) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f == 0) *fcount = 0;
+  if (f < n_frames) { stat[f] = 0; tg[f] = 0; fo[f] = 0.0; ifo[f] = 0; }
+}
+
 template <typename T>
 __global__ void t4_fill_ones_kernel(cx<T>* __restrict__ h, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) h[i] = mk<T>(1, 0);
@@ -773,10 +803,8 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   dres = arena + o_res; dresv = arena + o_resv; dy = arena + o_y; dX = arena + o_X; dest = arena + o_est;
   dhp = arena + o_hp; dH = arena + o_H;
   void* dXp = arena + o_Xp;
-  OFDM_HIP(hipMemsetAsync(dstat, 0, sizeof(int32_t) * F, s));
-  OFDM_HIP(hipMemsetAsync(dtg, 0, sizeof(int64_t) * F, s));
-  OFDM_HIP(hipMemsetAsync(dfo, 0, sizeof(double) * F, s));
-  OFDM_HIP(hipMemsetAsync(difo, 0, sizeof(int32_t) * F, s));
+  // per-frame scalars and the unresolved-frame counter start at zero: one launch instead of five memsets (4.7 us each)
+  hipLaunchKernelGGL(t4_init_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, dstat, dtg, dfo, difo, (int32_t*)(arena + o_flist), F);
   if (sync) {
     OFDM_ARG(n_out > 0 && Tg >= 1 && Tg <= ACF_MAXW, "rx_chain_task4: frame shorter than T_guard + Nfft, or T_guard outside 1..%d", ACF_MAXW);
     drho = arena + o_rho;
@@ -786,20 +814,20 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     // not settle (ok = 0) are redone over the whole stream, the others leave that second pass at its first instruction.
     const int64_t n_pref = std::min<int64_t>(n_out, ((3 * (int64_t)(N + Tg) + ACF_TILE - 1) / ACF_TILE) * ACF_TILE);
     const bool two_pass = n_pref < n_out && !getenv("OFDM_T4_FULL_ACF");
+    OFDM_TRY(acf_prepare<T>());
     if (two_pass) {
-      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_pref, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_pref, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s, (const cx<T>*)drx, len, Tg,
                          N, (cx<T>*)drho, n_pref, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
       hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_pref, Tg, 0.77,
                          (int64_t*)dres, (double*)dresv, n_out, 0);
     }
     if (two_pass) {
       int32_t* dfl = (int32_t*)(arena + o_flist);                // [0] = count, [1..] = frames still to do
-      OFDM_HIP(hipMemsetAsync(dfl, 0, sizeof(int32_t), s));
       hipLaunchKernelGGL(t4_unresolved_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, F, dfl + 1, dfl);
-      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)std::min<int64_t>(F, 8)), dim3(ACF_THREADS), 0, s,
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)std::min<int64_t>(F, 8)), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s,
                          (const cx<T>*)drx, len, Tg, N, (cx<T>*)drho, n_out, n_out, (const int32_t*)(dfl + 1), (const int32_t*)dfl);
     } else {
-      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), 0, s, (const cx<T>*)drx, len, Tg,
+      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s, (const cx<T>*)drx, len, Tg,
                          N, (cx<T>*)drho, n_out, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
     }
     hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
@@ -965,14 +993,15 @@ int ofdm_AutoCorrFunction(const void* rx, int64_t len, int width_window, int nff
   OFDM_TRY(st.fetch(res, sizeof(res), &dres));
   OFDM_TRY(st.fetch(resv, sizeof(resv), &dresv));
   const unsigned grid = cdiv_u(n_out, ACF_TILE);
+  OFDM_TRY(f64 ? acf_prepare<double>() : acf_prepare<float>());
   if (f64) {
-    hipLaunchKernelGGL(acf_kernel<double>, dim3(grid), dim3(ACF_THREADS), 0, ctx().stream, (const c64*)dx, len,
+    hipLaunchKernelGGL(acf_kernel<double>, dim3(grid), dim3(ACF_THREADS), acf_lds_bytes<double>(width_window), ctx().stream, (const c64*)dx, len,
                        width_window, nfft, (c64*)drho, n_out);
     OFDM_TRY(check_launch("acf_kernel"));
     hipLaunchKernelGGL(acf_plateau_kernel<double>, dim3(1), dim3(PLAT_THREADS), 0, ctx().stream, (const c64*)drho,
                        n_out, width_window, 0.77, (int64_t*)dres, (double*)dresv);
   } else {
-    hipLaunchKernelGGL(acf_kernel<float>, dim3(grid), dim3(ACF_THREADS), 0, ctx().stream, (const c32*)dx, len,
+    hipLaunchKernelGGL(acf_kernel<float>, dim3(grid), dim3(ACF_THREADS), acf_lds_bytes<float>(width_window), ctx().stream, (const c32*)dx, len,
                        width_window, nfft, (c32*)drho, n_out);
     OFDM_TRY(check_launch("acf_kernel"));
     hipLaunchKernelGGL(acf_plateau_kernel<float>, dim3(1), dim3(PLAT_THREADS), 0, ctx().stream, (const c32*)drho,
