@@ -119,14 +119,10 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
   }
 }
 
-// dynamic LDS beyond 64 KB (double table at WidthWindow = 1024) has to be allowed once per kernel
+// dynamic LDS beyond 64 KB (double table at WidthWindow = 1024) has to be allowed for the kernel (per device: set on every call)
 template <typename T>
 static int acf_prepare() {
-  static bool done = false;
-  if (!done) {
-    OFDM_HIP(hipFuncSetAttribute((const void*)acf_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acf_lds_bytes<T>(ACF_MAXW)));
-    done = true;
-  }
+  OFDM_HIP(hipFuncSetAttribute((const void*)acf_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acf_lds_bytes<T>(ACF_MAXW)));
   return OFDM_OK;
 }
 
