@@ -360,7 +360,13 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
           const int k = pv.pc0[i % (unsigned)pv.np];
           const double t = tau * (double)k;
           double sn, cs;
-          sincospi(2.0 * (t - floor(t)), &sn, &cs);
+          if constexpr (sizeof(T) == 4) {                          // throughput mode: phase reduced in double, sine / cosine in float
+            float fs, fc;
+            sincospif(2.0f * (float)(t - floor(t)), &fs, &fc);
+            sn = fs; cs = fc;
+          } else {
+            sincospi(2.0 * (t - floor(t)), &sn, &cs);
+          }
           const double r2 = qr[u] * cs + qi[u] * sn, i2 = qi[u] * cs - qr[u] * sn;
           qr[u] = r2; qi[u] = i2;
         }
