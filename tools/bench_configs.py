@@ -111,9 +111,9 @@ def c3():
            "ms_per_frame": ms, "sym_per_s": N_symb / ms * 1e3, "TgPosition": int(pos), "IFO": float(ifo),
            "BER": float(ofdm.BER_func(torch.from_numpy(bits).to(dev), out)),
            "note": "per_call = one 50-symbol frame per call sequence (11 launches + 3 host scalars), launch-latency bound; "
-                   "batched = ofdm_rx_chain_task4 over 1024 frames with their own STO / CFO draws"}
+                   "batched = ofdm_rx_chain_task4 over 4096 frames with their own STO / CFO draws (1024 frames per call: 0.53 of the HBM peak, 4096: 0.60, 8192: 0.57)"}
     # batched form: the same receiver over many frames in one call (ofdm_rx_chain_task4), each frame its own STO / CFO
-    F = 1024
+    F = 4096
     rng = np.random.default_rng(3)
     plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, pv[:, 0], int(np.ceil(N_carrier / 6)), 3, const,
                        precision="fp32", device=0)

@@ -26,8 +26,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c
 C5_WARM_S=0.02 bash tools/pmc_cmd.sh $out/c5_pmc python tools/c5_run.py 2048 5 > $out/c5_pmc_summary.txt 2>&1
 timeout -k 10 300 python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 2 --frames-per-tile 64 --json $out/sweep_c5.json > /dev/null 2>&1
 step c3
-timeout -k 10 300 python tools/c3_run.py 1024 20 > $out/c3.txt 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_stats -- python tools/c3_run.py 1024 20 > /dev/null 2>&1 && cp $out/c3_stats/*/*kernel_stats.csv $out/c3_kernel_stats.csv
+timeout -k 10 300 python tools/c3_run.py 4096 10 > $out/c3.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_stats -- python tools/c3_run.py 4096 10 > /dev/null 2>&1 && cp $out/c3_stats/*/*kernel_stats.csv $out/c3_kernel_stats.csv
 step part2
 timeout -k 10 400 python tools/part2_run.py --precision fp32 > $out/part2.txt 2>&1
 timeout -k 10 300 python tools/part2_run.py --random --precision fp32 > $out/part2_random.txt 2>&1
