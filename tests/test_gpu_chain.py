@@ -324,6 +324,52 @@ def test_chain_many_taps_fast_path(ofdm, oracle):
     assert np.array_equal(np.asarray(out["errors"]).astype(np.int64), ref["errors"])
 
 
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+@pytest.mark.parametrize("nfft,nc,comb,taps_n", [(1024, 400, 4, 9), (2048, 512, 2, 17), (4096, 1024, 4, 25), (2048, 500, 4, 31)])
+def test_chain_long_pursuits(ofdm, oracle, precision, nfft, nc, comb, taps_n):
+    """9..32 taps = the one-wavefront-per-frame pursuit of omp_wave_core.hpp (picks in lanes, R = L^-1 over a cleared triangle):
+    K = 100, 256, 256, 125 atoms (not multiples of 64), odd tap counts, ragged batch.  fp64: the oracle's picks, H and bits;
+    fp32: every pick the arg-max or a near-tie (SURVEY 8c rule, pick_audit.py), H = the refit on the device's picks."""
+    from ofdm_course_amd import frames as fr
+    from pick_audit import omp_pick_audit
+    rng = np.random.default_rng(nfft + taps_n)
+    K = int(np.ceil(nc / comb))
+    d = np.sort(rng.choice(min(K - 1, nfft // 8 - 1), taps_n, replace=False))
+    d[0] = 0
+    taps = np.stack([d.astype(float), rng.uniform(0.25, 1.0, taps_n) * np.exp(-d / (nfft / 16))], axis=1)
+    cfg = fr.FrameConfig(f"t{taps_n}", nfft, nc, comb, "16QAM", N_symb=3, taps=taps, dominant_taps=taps_n)
+    cfg.SNR_dB = 30.0
+    nfr = 7
+    data = fr.make_frames(cfg, ofdm, nfr, seed=taps_n, precision=precision)
+    plan = fr.make_plan(cfg, ofdm, precision=precision)
+    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=True)
+    rx64 = np.asarray(data["rx"]).astype(np.complex128)
+    ref = oracle.rx_chain_task5(rx64, cfg.Nfft, cfg.T_guard, cfg.N_carrier, cfg.pilotCarriers, cfg.dataCarriers, data["pilots"],
+                                cfg.K, cfg.dominant_taps, cfg.Constellation, ref_bits=data["bits"])
+    idx = np.asarray(out["index"]).T
+    H = np.asarray(out["H"]).T
+    if precision == "fp64":
+        for f in range(nfr):
+            want = list(ref["index"][f])
+            assert list(idx[f][: len(want)]) == want and not idx[f][len(want):].any()
+        assert rel_l2(H, ref["H"]) < 1e-8
+        assert np.array_equal(np.asarray(out["errors"]).astype(np.int64), ref["errors"])
+        return
+    Smat = oracle.sensing_matrix(cfg.pilotCarriers, cfg.Nfft, cfg.K)
+    pc = np.asarray(cfg.pilotCarriers, int) - 1
+    L = cfg.Nfft + cfg.T_guard
+    near_total = 0
+    for f in range(nfr):
+        got = [int(k) for k in idx[f] if k > 0]
+        X1 = oracle.OFDM_demodulator(rx64[:L, f][:, None], cfg.T_guard)
+        near, H_refit = omp_pick_audit(oracle, X1[pc, 0] / data["pilots"], Smat, got, cfg.Nfft)
+        near_total += near
+        assert rel_l2(H[f], H_refit[:cfg.N_carrier]) < 3e-4, f
+        if near == 0:
+            assert got == list(ref["index"][f])[: len(got)]
+    print(f"{taps_n} taps fp32: {near_total} near-tied picks of {nfr * taps_n}")
+
+
 def test_chain_full_size_properties(ofdm):
     """BASELINE size (8192 frames = 114688 symbols of config M): size-independent properties.
     (1) the error counter equals popcount(bits xor reference) recomputed from the packed outputs,
