@@ -558,6 +558,7 @@ struct FastPlanView {
   void** ws_h;             // MMSE mode workspace: H [n_frames][n_carrier]
   void** ws_x;             // split path workspace: X(1..N_carrier, :) of every symbol [n_frames * n_symb][n_carrier]
   int64_t* ws_x_elems;
+  int data_mod4;           // bit r: a data carrier with 0-based index = r (mod 4) exists (the wave symbol kernel skips the other residues)
 };
 
 template <typename T>

@@ -404,11 +404,13 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
   pl->frame_words = (int)((frame_bits + 31) / 32);
   std::vector<int16_t> prole(nfft, -1), drole(nfft, -1);
   std::vector<int32_t> pc0(n_pilots);
-  int rc = OFDM_OK;
+  int rc = OFDM_OK, mod4 = 0;
   for (int d = 0; d < n_data && rc == OFDM_OK; ++d) {
     if (data_carriers[d] < 1 || data_carriers[d] > n_carrier) { set_error("rx_plan_create: data carrier outside 1..N_carrier"); rc = OFDM_ERR_ARG; break; }
     drole[data_carriers[d] - 1] = (int16_t)d;
+    mod4 |= 1 << ((data_carriers[d] - 1) & 3);
   }
+  pl->data_mod4 = mod4;
   for (int p = 0; p < n_pilots && rc == OFDM_OK; ++p) {
     if (pilot_carriers[p] < 1 || pilot_carriers[p] > nfft) { set_error("rx_plan_create: pilot carrier outside 1..Nfft"); rc = OFDM_ERR_ARG; break; }
     pc0[p] = pilot_carriers[p] - 1;

@@ -24,6 +24,7 @@
 // a register prefetch that costs no registers and no copies (the four-wavefront form copies 16 VGPRs per symbol).
 // Two LDS round trips per sample instead of three; 2 x 32 + 31 + ... wave-instructions on the LDS pipe per symbol.
 #include <algorithm>
+#include <type_traits>
 
 #include "chain_fast_core.hpp"
 
@@ -61,6 +62,14 @@ __device__ __forceinline__ cx<float> w32(int m) {
   }
 }
 
+// Register that holds element (class j0, position m) of the 32-point register transform -- sample j0 + 4 m before the dft8s,
+// (j0, ka = m) after them, Z[ka + 8 kb] = (kb = j0, ka = m) after the dft4s:
+//   layout 0: j0 + 4 m                          (a class is a stride-4 set, a position a quad)
+//   layout 1: 4 j0 + 16 (m >> 2) + (m & 3)      (a class is two quads, a position a stride-4 set)
+// Round r reads the positions ka = r, r + 4 of every class: in layout 0 the quads r and r + 4 = class r of layout 1, in layout 1
+// the registers = r (mod 4) = class r of layout 0.
+__host__ __device__ constexpr int wv_reg(int L, int j0, int m) { return L == 0 ? j0 + 4 * m : 4 * j0 + 16 * (m >> 2) + (m & 3); }
+
 // LUT: level rank by arithmetic guess + the two neighbouring thresholds from LDS (demap_square_lut) instead of counting all
 // 2^BA - 1 thresholds
 // SL = 0: count all 2^BA - 1 thresholds (demap_square); 1: LUT; 2: arithmetic rank around the exactly compared centre
@@ -71,7 +80,7 @@ __device__ __forceinline__ int slice_wave(const DemapTable<float>& tab, const fl
   else return slice_symbol<float, BA, true>(tab, z);
 }
 
-template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, int LUT = 2>
+template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, int LUT = 2, int SKIP = 0>
 __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_kernel(FastParams<float> P, WaveLayout lay,
                                                                   const cx<float>* __restrict__ rx, int64_t n_frames,
                                                                   uint32_t* __restrict__ bits_out,
@@ -105,9 +114,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
   const int Lsym = WV_N + P.t_guard;
   const int64_t Lframe = (int64_t)Lsym * n_symb;
   const int CB = lay.cb;
-  // carriers of this lane: round r, kb -> k = 32 (ka + 8 kb) + 8 r + c,  lane = 8 c + ka
+  // carriers of this lane: round r, kb -> k = 32 (ka + 8 kb) + r + 4 c,  lane = 8 c + ka  (a round = the kj = r + 4 c, c < 8:
+  // one residue class mod 4 of the carriers -- a comb-4 pilot class is a whole round, which data symbols then skip)
   const int c_out = lane >> 3, ka_out = lane & 7;
-  auto kk_of = [&](int t) { return 32 * (ka_out + 8 * (t & 1)) + 8 * (t >> 1) + c_out; };
+  auto kk_of = [&](int t) { return 32 * (ka_out + 8 * (t & 1)) + (t >> 1) + 4 * c_out; };
   // data position of output t (or 0xffff): table [4 rounds][64 lanes], two to a word, the same for every wavefront
   if (wave == 0) {
 #pragma unroll
@@ -156,11 +166,16 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
       for (int c = 0; c < 8; ++c) w[c] = nt_load(src + 64 * (4 * c + 3));
     }
   }
-  for (int64_t f = wave_id; f < n_frames; f += n_waves) {
+  // One frame whose first transform finds its samples in register layout S0 (wv_reg).  The symbol loop takes the transforms in
+  // pairs (layout S0, then the other), so its back-edge always carries layout S0: every register index is static and no value
+  // ever changes registers.  (A run-time choice of the layout per symbol made the allocator permute 32 values at the join:
+  // 2600 spill instructions, 1.6x slower.)
+  auto do_frame = [&](auto SC, int64_t f) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(SC)::value;
     const cx<T>* frx = rx + f * Lframe;
     const int64_t fnext = f + n_waves;
-    // ---- G = 1 ./ H on this lane's carriers (OMP_estimate.m:36, equalize_signal.m:6)
     cx<T> geq[8];
+    // ---- G = 1 ./ H on this lane's carriers (OMP_estimate.m:36, equalize_signal.m:6)
     if constexpr (HEXT) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -208,70 +223,87 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
     unsigned err = 0;
     int slot = 1;                                                      // symbols in the codes buffer
     int64_t code0 = 0;                                                 // first code index of the buffer within the frame
-    for (int s = 1; s < n_symb; ++s) {
+    auto symbol = [&](auto LC, int s) __attribute__((always_inline)) {
+      constexpr int L = decltype(LC)::value;
       // where the registers of a finished round are refilled from: the next symbol of this wavefront's stream
       // (past the last symbol of the last frame: the same symbol again, so that the loads are unconditional)
       const cx<T>* nsrc = frx + (int64_t)s * Lsym + P.t_guard + lane;
       if (s + 1 < n_symb) nsrc += Lsym;
       else if (fnext < n_frames) nsrc = rx + fnext * Lframe + Lsym + P.t_guard + lane;
-      // ---- 1. 32-point DFT over j = j0 + 4 j1 in registers: Z[ka + 8 kb] ends in v[4 ka + kb]
-#pragma unroll
-      for (int j0 = 0; j0 < 4; ++j0) {
-        if (WBUF && j0 == 3) {
-          // transform the look-ahead registers where they are, hand the results to the (free) slots j = 4 c + 3, THEN refill
-          dft8<T, false>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[4 * c + 3] = w[c];
-          if constexpr (ABL != 1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) w[c] = nt_load(nsrc + 64 * (4 * c + 3));
-          }
-        } else {
-          dft8<T, false>(v[j0], v[j0 + 4], v[j0 + 8], v[j0 + 12], v[j0 + 16], v[j0 + 20], v[j0 + 24], v[j0 + 28]);
-        }
-        if (j0 > 0) {
-#pragma unroll
-          for (int ka = 1; ka < 8; ++ka) v[j0 + 4 * ka] = v[j0 + 4 * ka] * w32(j0 * ka);
-        }
-      }
-#pragma unroll
-      for (int ka = 0; ka < 8; ++ka) dft4<T, false>(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3]);
-      // ---- 2.-3. four rounds of eight kj = 8 r + c  (kb = r, ka = c: register v[4 c + r])
       uint8_t* const cslot = codes + slot * nd;
+      // One transform in register layout L (wv_reg): round r reads -- and thereby frees -- exactly the registers that hold
+      // class r of the NEXT transform in the other layout, so the layouts alternate and every register index stays static.
+      {
+        // ---- 1. 32-point DFT over j = j0 + 4 j1 in registers: element (j0, ka) after the four dft8, Z[ka + 8 kb] after the dft4
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cx<T> z_keep[8];
+        for (int j0 = 0; j0 < 4; ++j0) {
+          if (WBUF && j0 == 3) {
+            // transform the look-ahead registers where they are, hand the results to the (free) slots of class 3, THEN refill
+            dft8<T, false>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int kj = 8 * r + c;
-          const cx<T> z = kj == 0 ? v[4 * c + r] : v[4 * c + r] * tw32_at(kj - 1);
-          t1w[72 * c] = z;
-          z_keep[c] = z;
+            for (int ka = 0; ka < 8; ++ka) v[wv_reg(L, 3, ka)] = w[ka];
+            if constexpr (ABL != 1) {
+#pragma unroll
+              for (int m = 0; m < 8; ++m) w[m] = nt_load(nsrc + 64 * (3 + 4 * m));
+            }
+          } else {
+            dft8<T, false>(v[wv_reg(L, j0, 0)], v[wv_reg(L, j0, 1)], v[wv_reg(L, j0, 2)], v[wv_reg(L, j0, 3)], v[wv_reg(L, j0, 4)],
+                           v[wv_reg(L, j0, 5)], v[wv_reg(L, j0, 6)], v[wv_reg(L, j0, 7)]);
+          }
+          if (j0 > 0) {
+#pragma unroll
+            for (int ka = 1; ka < 8; ++ka)
+              if (!((SKIP >> (ka & 3)) & 1)) v[wv_reg(L, j0, ka)] = v[wv_reg(L, j0, ka)] * w32(j0 * ka);
+          }
         }
-        // the round's registers are free: next symbol's samples j = 4 c + r
-        if constexpr (ABL == 1) {                                    // diagnostic build: issue time without the sample stream
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[4 * c + r] = mk<T>(z_keep[c].y, z_keep[c].x);
-        } else if (!(WBUF && r == 3)) {
+        for (int ka = 0; ka < 8; ++ka)
+          if (!((SKIP >> (ka & 3)) & 1))
+            dft4<T, false>(v[wv_reg(L, 0, ka)], v[wv_reg(L, 1, ka)], v[wv_reg(L, 2, ka)], v[wv_reg(L, 3, ka)]);
+        // ---- 2.-3. four rounds of eight kj = r + 4 c  (ka = r + 4 (c & 1), kb = c >> 1)
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[4 * c + r] = nt_load(nsrc + 64 * (4 * c + r));
+        for (int r = 0; r < 4; ++r) {
+          const bool skip = (SKIP >> r) & 1;                          // compile-time after unrolling
+          cx<T> z_keep[8];
+          if (!skip) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int kj = r + 4 * c, ka = r + 4 * (c & 1), kb = c >> 1;
+              const cx<T> z = kj == 0 ? v[wv_reg(L, kb, ka)] : v[wv_reg(L, kb, ka)] * tw32_at(kj - 1);
+              t1w[72 * c] = z;
+              z_keep[c] = z;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) z_keep[c] = v[wv_reg(L, c >> 1, r + 4 * (c & 1))];
+          }
+          // the round's registers are free: next symbol's samples of class r, in the other layout
+          if constexpr (ABL == 1) {                                  // diagnostic build: issue time without the sample stream
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[wv_reg(1 - L, r, m)] = mk<T>(z_keep[m].y, z_keep[m].x);
+          } else if (!(WBUF && r == 3)) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[wv_reg(1 - L, r, m)] = nt_load(nsrc + 64 * (r + 4 * m));
+          }
+          if (!skip) {
+            wave_sync();
+            cx<T> u[8];
+            lds_read8<8, true>(u, t1r);
+            wave_sync();
+            dft8<T, false>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+#pragma unroll
+            for (int t = 1; t < 8; ++t) u[t] = u[t] * twbl_at(t - 1);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) t2w[t] = u[t];
+            wave_sync();
+            lds_read8<65, true>(u, t2r);
+            wave_sync();
+            dft8_first2<T>(u);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+              *code_ptr(cslot, 2 * r + kb) = (uint8_t)slice_wave<BA, LUT>(tab, lut, u[kb] * geq[2 * r + kb]);
+          }
         }
-        wave_sync();
-        cx<T> u[8];
-        lds_read8<8, true>(u, t1r);
-        wave_sync();
-        dft8<T, false>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
-#pragma unroll
-        for (int t = 1; t < 8; ++t) u[t] = u[t] * twbl_at(t - 1);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) t2w[t] = u[t];
-        wave_sync();
-        lds_read8<65, true>(u, t2r);
-        wave_sync();
-        dft8_first2<T>(u);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-          *code_ptr(cslot, 2 * r + kb) = (uint8_t)slice_wave<BA, LUT>(tab, lut, u[kb] * geq[2 * r + kb]);
       }
       ++slot;
       // ---- pack a full batch (or the frame's last one): bit i of the frame -> byte i/8, bit 7 - i%8; BER numerator
@@ -288,6 +320,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
         code0 += n_codes;
         slot = 0;
       }
+    };
+    for (int s = 1; s < n_symb; s += 2) {
+      symbol(std::integral_constant<int, S0>{}, s);
+      if (s + 1 < n_symb) symbol(std::integral_constant<int, 1 - S0>{}, s + 1);     // (an odd count leaves through here)
     }
     if (n_symb == 1) {                                                 // only the stash symbol
       const int n_codes = nd, pad_to = (n_codes + 31) & ~31;
@@ -300,6 +336,17 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
     if (ref_bits && errors_out) {
       for (int off = 32; off > 0; off >>= 1) err += __shfl_xor(err, off, 64);
       if (lane == 0) errors_out[f] = err;
+    }
+  };
+  // a frame of an odd number of transforms leaves the samples of the next frame in the other layout
+  const bool odd = ((n_symb - 1) & 1) != 0;
+  for (int64_t f = wave_id; f < n_frames;) {
+    do_frame(std::integral_constant<int, 0>{}, f);
+    f += n_waves;
+    if (odd) {
+      if (f >= n_frames) break;
+      do_frame(std::integral_constant<int, 1>{}, f);
+      f += n_waves;
     }
   }
 }
@@ -333,8 +380,8 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
                            const void* ref, void* errs, void* h_out, void* idx_out) {
   // two builds of the kernel: 4 wavefronts per workgroup at <= 168 VGPRs (three workgroups = 12 wavefronts per CU) and
   // 8 per workgroup at <= 128 VGPRs (two workgroups = 16 wavefronts per CU)
-  int wpb = WV_WPB;
-  if (const char* e = getenv("OFDM_WAVE_WPB")) wpb = atoi(e) == 8 ? 8 : 4;
+  const int wpb = WV_WPB;       // (eight wavefronts per workgroup at <= 128 VGPRs, the LUT slicer and the form without look-ahead
+                                //  registers were measured in round 2 -- 965 / 937 / +1.5 % against 911 us -- and are no longer built)
   WaveLayout lay;
   OFDM_ARG(wave_layout(pv.nd, pv.n_symb, wpb, lay), "rx_chain_task5(wave): frame does not fit the wave-per-frame stage");
   DemapTable<float> tab;
@@ -350,12 +397,13 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
     return OFDM_OK;
   };
   const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
-  const bool nowb = getenv("OFDM_WAVE_NO_WBUF") != nullptr, uselut = getenv("OFDM_WAVE_LUT") != nullptr, exact = getenv("OFDM_WAVE_EXACT_SLICER") != nullptr;   // LUT slicer: measured 3 % slower at 64-QAM here (7 thresholds per axis)
+  const bool exact = getenv("OFDM_WAVE_EXACT_SLICER") != nullptr;
+  // no data carrier with index = 0 (mod 4) -- pilots "1:4:end", the benchmark layout: the round of that residue class is not
+  // computed on data symbols (a quarter of the post-register work and of the register transform's second stage)
+  const bool skip0 = (pv.data_mod4 & 15) == 14 && !getenv("OFDM_WAVE_NO_SKIP");
 #define WAVE_CASE(BAV, HX)                                                                \
-  if (wpb == 8) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 8>));                     \
-  else if (nowb) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, false, 0>));          \
-  else if (uselut) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 1>));   \
-  else if (exact) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 0>));   \
+  if (exact) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 0>));            \
+  else if (skip0) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 2, 1>));    \
   else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4>))
   if (mmse) {
     switch (ba) {

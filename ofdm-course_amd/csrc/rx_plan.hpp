@@ -19,6 +19,7 @@ struct ofdm_rx_plan {
   void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
   int m_pad = 0;
   std::vector<int32_t> pilot_loc;      // 1-based, as given
+  int data_mod4 = 15;                  // bit r set: some data carrier has (0-based) index = r mod 4
   int64_t ws_frames = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int timing = 0;          // ofdm_rx_plan_set_timing
@@ -60,4 +61,5 @@ inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {
   pv.fused_out = &pl->last_fused;
   pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
   pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
+  pv.data_mod4 = pl->data_mod4;
 }
