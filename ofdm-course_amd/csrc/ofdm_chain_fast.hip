@@ -231,6 +231,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? (NW <= 4 ? 5 : 
     kk[t] = NW * (lane + 64 * t) + wave;
     dd[t] = kk[t] < P.n_carrier ? (int)P.drole[kk[t]] : -1;
   }
+  // Sub-transform `wave` yields the carriers = wave (mod NW).  With comb pilots whose period is a multiple of NW's divisor
+  // (the benchmark layouts: pilots 1:4:end, NW = 4 or 8) some wavefronts own pilot carriers only: on data symbols they keep
+  // the barriers company and skip their 512-point transform.
+  bool mine = false;
+#pragma unroll
+  for (int t = 0; t < NOUT; ++t) mine = mine || dd[t] >= 0;
+  const bool wave_has_data = __any(mine) != 0;
   const int Lsym = N + P.t_guard;
   const int taps = P.taps, bps = P.bps, nd = P.nd;
   const int64_t frame_bits = (int64_t)nd * P.n_symb * bps;
@@ -302,12 +309,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? (NW <= 4 ? 5 : 
         __syncthreads();                 // every wavefront has finished its previous transform (region reuse)
         dif_scatter<T, NW>(v, gid, ex);
         __syncthreads();
-        dif_gather<T, true>(v, wave, lane, ex);
+        if (wave_has_data) dif_gather<T, true>(v, wave, lane, ex);
       }
-      wave_fft512<T, PRUNE2, true, true>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+      if (wave_has_data) {                                             // wavefront-uniform
+        wave_fft512<T, PRUNE2, true, true>(v, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
-      for (int t = 0; t < NOUT; ++t)
-        if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)slice_symbol<T, BA>(tab, v[t] * geq[t]);
+        for (int t = 0; t < NOUT; ++t)
+          if (dd[t] >= 0) codes[s * nd + dd[t]] = (uint8_t)slice_symbol<T, BA>(tab, v[t] * geq[t]);
+      }
     }
     __syncthreads();
     // ---- pack (bit i of the frame -> byte i/8, bit 7-i%8) + BER numerator.  A group of 32 decided
