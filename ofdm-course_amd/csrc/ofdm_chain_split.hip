@@ -180,7 +180,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
                                                              const cx<T>* __restrict__ tw4096, const cx<T>* __restrict__ tw8192,
                                                              int64_t n_symb, int t_guard, int n_keep,
                                                              cx<T>* __restrict__ ypil /* or null */, const int32_t* __restrict__ pc0,
-                                                             const cx<T>* __restrict__ pilots, int np, int n_symb_frame) {
+                                                             const cx<T>* __restrict__ pilots, int np, int n_symb_frame,
+                                                             const int16_t* __restrict__ drole /* or null: every row is wanted */) {
   constexpr int NW = 8;
   constexpr int psh = 4;                                       // staging pad: one element every 16
   constexpr int NOUT = PRUNE2 ? 2 : 8;
@@ -197,9 +198,25 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
   for (int t = 1; t < 8; ++t) twb[t - 1] = tw4096[(t * (lane & 7) * 8) * NW];
 #pragma unroll
   for (int t = 0; t < 8; ++t) w2[t] = tw8192[gid + 512 * t];
+  // rows of this wavefront: even half 2 k', odd half 2 k' + 1, k' = NW (lane + 64 t) + wave.  A half whose rows hold no data
+  // carrier (comb pilots 1:4:end: the even half of every even wavefront) is only needed on a frame's first symbol (pilot LS):
+  // on the other symbols the wavefront skips that 512-point transform (the rows it would have produced are never read).
+  bool even_data = true, odd_data = true;
+  if (drole) {
+    bool e = false, o = false;
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) {
+      const int k = 2 * (NW * (lane + 64 * t) + wave);
+      e = e || (k < n_keep && drole[k] >= 0);
+      o = o || (k + 1 < n_keep && drole[k + 1] >= 0);
+    }
+    even_data = __any(e) != 0;
+    odd_data = __any(o) != 0;
+  }
   __syncthreads();
   for (int64_t s = blockIdx.x; s < n_symb; s += gridDim.x) {
     const cx<T>* src = y + s * (int64_t)(8192 + t_guard) + t_guard;
+    const bool first_of_frame = (unsigned)s % (unsigned)n_symb_frame == 0u;
     cx<T> a[8], b[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { a[t] = nt_load(src + gid + 512 * t); b[t] = nt_load(src + gid + 512 * t + 4096); }
@@ -215,19 +232,29 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
     __syncthreads();                                           // previous symbol's staged rows have been written out
     dif_scatter<T, NW>(a, gid, ex);
     __syncthreads();
-    dif_gather<T>(a, wave, lane, ex);
-    wave_fft512<T, PRUNE2>(a, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+    if (even_data || first_of_frame) {                         // wavefront-uniform
+      dif_gather<T>(a, wave, lane, ex);
+      wave_fft512<T, PRUNE2>(a, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
-    for (int t = 0; t < NOUT; ++t) oe[t] = a[t];
+      for (int t = 0; t < NOUT; ++t) oe[t] = a[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t) oe[t] = mk<T>(0, 0);
+    }
     // odd bins
     dif_stage<T, NW>(b, dt);
     __syncthreads();
     dif_scatter<T, NW>(b, gid, ex);
     __syncthreads();
-    dif_gather<T>(b, wave, lane, ex);
-    wave_fft512<T, PRUNE2>(b, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+    if (odd_data || first_of_frame) {
+      dif_gather<T>(b, wave, lane, ex);
+      wave_fft512<T, PRUNE2>(b, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
 #pragma unroll
-    for (int t = 0; t < NOUT; ++t) oo[t] = b[t];
+      for (int t = 0; t < NOUT; ++t) oo[t] = b[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t) oo[t] = mk<T>(0, 0);
+    }
     __syncthreads();                                           // every wavefront is done with its private region
     // bin k' = NW (lane + 64 t) + wave of each half  ->  rows 2k' (even) and 2k'+1 (odd); staged in pieces of STG rows.
     // Neighbouring lanes hold rows 16 apart: the staging index is padded by one element every 16 (row i at i + i/16), which
@@ -260,7 +287,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
 
 template <typename T>
 static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guard, int n_keep, void* ypil, const int32_t* pc0,
-                              const void* pilots, int np, int n_symb_frame) {
+                              const void* pilots, int np, int n_symb_frame, const void* drole) {
   const void *tw4 = nullptr, *tw8 = nullptr;
   OFDM_ARG(n_symb < (int64_t)1 << 31, "rx_chain_task5: more than 2^31 symbols in one call");
   OFDM_TRY(get_twiddles(4096, std::is_same<T, double>::value, &tw4));
@@ -270,7 +297,8 @@ static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guar
     const int per_cu = resident_blocks_per_cu((const void*)kern, 512, dyn);
     const unsigned grid = (unsigned)std::min<int64_t>(n_symb, (int64_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), dyn, ctx().stream, (const cx<T>*)y, (cx<T>*)x, (const cx<T>*)tw4,
-                       (const cx<T>*)tw8, n_symb, t_guard, n_keep, (cx<T>*)ypil, pc0, (const cx<T>*)pilots, np, n_symb_frame);
+                       (const cx<T>*)tw8, n_symb, t_guard, n_keep, (cx<T>*)ypil, pc0, (const cx<T>*)pilots, np, n_symb_frame,
+                       (const int16_t*)drole);
     return check_launch("demod_keep8192_kernel");
   };
   if (n_keep <= 2048) return launch(demod_keep8192_kernel<T, true>);
@@ -341,8 +369,10 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   if (pv.nfft == 8192 && !getenv("OFDM_SPLIT_GENERIC_FFT")) {
     // the pilot LS values come out of the transform of each frame's first symbol (no pilot_ls pass)
     const bool fuse = !getenv("OFDM_SPLIT_NO_PLS_FUSE");
+    // the rows of pilot-only sub-transforms are skipped on data symbols -- only when the pilot LS values come out of this
+    // kernel (the separate pilot_ls pass and h_out-less consumers read the data rows and the first symbol's pilots only)
     OFDM_TRY(demod_keep8192_run<T>(rx, xk, n_frames * pv.n_symb, pv.t_guard, pv.n_carrier, fuse ? (void*)P.ypil : nullptr, d_pc0,
-                                   P.pilots, pv.np, pv.n_symb));
+                                   P.pilots, pv.np, pv.n_symb, fuse && !getenv("OFDM_SPLIT_ALL_ROWS") ? pv.d_drole : nullptr));
     if (!fuse) {
       hipLaunchKernelGGL(pilot_ls_kernel<T>, dim3(cdiv_u(n_frames * pv.np, 256)), dim3(256), 0, st, P, (const cx<T>*)xk, d_pc0,
                          n_frames);
