@@ -18,11 +18,17 @@
 //        carrier k = kj + 32 kl < 512 <=> kl < 16  (only carriers 1..N_carrier <= Nfft/4 are ever used)
 //      done in four rounds of eight kj through a wave-private 4.6 KB LDS region; both transposes are conflict-free
 //      under the per-instruction banking of MI355X_MICROARCH.md (checked by tools/lds_bank_check.py):
-//        T1: element 72 c + lane            (write, c = kj & 7) / 72 c' + 8 e + l0'   (read by lane 8 c' + l0', e = l1)
+//        T1: element 72 c + lane            (write, c = position of kj in its round) / 72 c' + 8 e + l0'   (read by lane 8 c' + l0', e = l1)
 //        T2: element 65 l0' + 8 c' + ka     (write)             / 65 e + lane         (read by lane 8 c'' + ka'', e = l0)
+// A round is one residue class of the carriers: round r = the kj = r + 4 c, c < 8, i.e. the carriers k = r (mod 4).  With the
+// pilots on 1:4:end (the benchmark layout) round 0 holds nothing but pilot carriers, which only a frame's first symbol needs
+// (it comes from the pilot stage's stash): data symbols skip that round and everything of the register transform that feeds it
+// (template parameter SKIP) -- a fifth of the instructions.
 // The registers of a round are dead once they are in LDS, so the NEXT symbol's samples are loaded straight into them:
-// a register prefetch that costs no registers and no copies (the four-wavefront form copies 16 VGPRs per symbol).
-// Two LDS round trips per sample instead of three; 2 x 32 + 31 + ... wave-instructions on the LDS pipe per symbol.
+// a register prefetch that costs no registers and no copies (the four-wavefront form copies 16 VGPRs per symbol).  With the
+// residue-class rounds the freed registers are the next class r in a DIFFERENT register layout (wv_reg), so the transform
+// exists in two layouts that alternate and the symbol loop runs in pairs.
+// Two LDS round trips per sample instead of three.
 #include <algorithm>
 #include <type_traits>
 
