@@ -407,9 +407,11 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
   // no data carrier with index = 0 (mod 4) -- pilots "1:4:end", the benchmark layout: the round of that residue class is not
   // computed on data symbols (a quarter of the post-register work and of the register transform's second stage)
   const bool skip0 = (pv.data_mod4 & 15) == 14 && !getenv("OFDM_WAVE_NO_SKIP");
+  const bool skip02 = (pv.data_mod4 & 15) == 10 && !getenv("OFDM_WAVE_NO_SKIP");      // pilots 1:2:end: two of the four rounds
 #define WAVE_CASE(BAV, HX)                                                                \
   if (exact) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 0>));            \
   else if (skip0) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 2, 1>));    \
+  else if (skip02) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 2, 5>));   \
   else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4>))
   if (mmse) {
     switch (ba) {
