@@ -187,12 +187,18 @@ def main():
     # clock / TLB settling before the W warm-up steps: a fresh process reaches its steady rate only after ~0.2 s of
     # back-to-back launches (20 timed steps right after 5 warm-up steps read 6-9 % low); untimed, reported as prewarm_steps
     prewarm_steps = 0
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
+    if args.prewarm_seconds > 0:
+        # ONE uninterrupted run of launches (a loop that synchronises every few steps keeps the part in its bursty clock
+        # state: the first ~20 steps of the timed region then read 10 % slow -- tools/step_profile.py): ten steps to learn
+        # the step time, then as many as fill the settling time, nothing waited for until the timed region's own bracket
+        t_pre = time.perf_counter()
         for _ in range(10):
             out = step()
         torch.cuda.synchronize()
-        prewarm_steps += 10
+        per_step = max((time.perf_counter() - t_pre) / 10, 1e-5)
+        prewarm_steps = 10 + int(min(args.prewarm_seconds / per_step, 5000))
+        for _ in range(prewarm_steps - 10):
+            out = step()
     for _ in range(args.warmup):
         out = step()
     reduce_counters(out)                       # warm the collective up as well

@@ -6,15 +6,15 @@ out=gpurun_out/evidence2; mkdir -p $out
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 step() { echo "== $1" >> $out/progress.txt; date >> $out/progress.txt; }
-step stats
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu --steps 300 --warmup 40 > $out/stats_bench.json 2> $out/stats.err || { echo "stats pass failed"; exit 1; }
-cp $out/stats/*/*kernel_stats.csv $out/final_kernel_stats.csv
 step pmc
 bash tools/pmc.sh $out/pmc > $out/final_pmc_summary.txt 2>&1 || { echo "pmc failed"; exit 1; }
 python tools/pmc_traffic.py $out/pmc > $out/traffic.json && mkdir -p profiles/round2 && cp $out/traffic.json profiles/round2/traffic.json
 step bench
-timeout -k 10 600 python bench.py > $out/final_bench.json 2> $out/bench.err || { echo "bench failed"; exit 1; }
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu > $out/bench_20steps.json 2>> $out/bench.err
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu > $out/bench_20steps.json 2> $out/bench.err
+timeout -k 10 600 python bench.py > $out/final_bench.json 2>> $out/bench.err || { echo "bench failed"; exit 1; }
+step stats
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu --steps 600 --warmup 40 > $out/stats_bench.json 2> $out/stats.err || { echo "stats pass failed"; exit 1; }
+cp $out/stats/*/*kernel_stats.csv $out/final_kernel_stats.csv
 step bench2
 timeout -k 10 600 python bench.py --gpus 2 --backend gloo --force-device 0 --steps 200 --warmup 20 --frames 8192 > $out/bench_gpus2_gloo_rehearsal.json 2> $out/bench2.err || echo "2-rank rehearsal failed"
 step clock
