@@ -89,6 +89,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? (PRUNE2 ? 4 : 3) : 2) voi
 struct OmpLayout {          // byte offsets into dynamic LDS
   unsigned off_y, off_c0, off_gram, off_state, off_fft, state_bytes, total;
   int fpw;                  // frames per wavefront
+  int c0_stride;            // row stride of c0 (k_atoms, or np + 1 when c0 overwrites Y in place)
+  int reg_c0;               // wave form with c0 by transform: c0 lands on Y's rows, moves to registers, and the R state takes the bytes
 };
 
 template <typename T>
@@ -105,11 +107,26 @@ static OmpLayout omp_layout(int np, int k_atoms, int taps, int fft_elems = 0) {
   o.fpw = fpw;
   const int fb = 4 * fpw;
   unsigned b = 0;
+  o.c0_stride = k_atoms;
+  o.reg_c0 = (wave && fft_elems > 0 && k_atoms <= 512 && k_atoms <= np + 1 && !getenv("OFDM_OMP_C0_LDS")) ? 1 : 0;
+  const unsigned fft_bytes = (unsigned)((sizeof(cx<T>) * (size_t)fft_elems + 15) & ~15u);
+  if (o.reg_c0) {
+    // Gram table | { Y rows (c0 written over them) + transform scratch }  ==  { R state of the four frames }: 41.8 KB instead of
+    // 74.8 KB at 32 taps, K = Np = 512 -- three resident workgroups per CU instead of two for a pursuit that is bound by the
+    // instruction issue of its (few) wavefronts
+    o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * gram_elems + 15) & ~15u);
+    o.off_y = b; o.off_c0 = b; o.c0_stride = np + 1;
+    const unsigned ybytes = (unsigned)((sizeof(cx<T>) * fb * (np + 1) + 15) & ~15u);
+    o.off_fft = b + ybytes;
+    o.off_state = b;
+    b += std::max<unsigned>(fb * o.state_bytes, ybytes + fft_bytes);
+    o.total = b;
+    return o;
+  }
   o.off_y = b;     b += (unsigned)((sizeof(cx<T>) * fb * (np + 1) + 15) & ~15u);   // rows padded by one element
   o.off_c0 = b;    b += (unsigned)((sizeof(cx<T>) * fb * k_atoms + 15) & ~15u);
   o.off_gram = b;  b += (unsigned)((sizeof(cx<T>) * gram_elems + 15) & ~15u);
   // the transform scratch of the c0 stage is dead before the per-frame OMP state is first written: same bytes
-  const unsigned fft_bytes = (unsigned)((sizeof(cx<T>) * (size_t)fft_elems + 15) & ~15u);
   o.off_state = b; o.off_fft = b;
   b += std::max<unsigned>(fb * o.state_bytes, fft_bytes);
   o.total = b;
@@ -146,10 +163,22 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
     for (int i = tid; i < K; i += 256) gl[i] = mk<T>((T)P.gram[i].x, (T)P.gram[i].y);
   }
   __syncthreads();
+  const int CS = lay.c0_stride;
+  // ||Y||^2 of this wavefront's frame(s) -- before c0 may overwrite Y (reg_c0 layout)
+  const int LPF = 64 / FPW;                      // lanes per frame
+  const int grp = lane / LPF, sl = lane - grp * LPF;
+  const int fi = wave * FPW + grp;               // frame slot inside the workgroup
+  double ynorm = 0;
+  {
+    const cx<T>* yf = Yl + fi * YS;
+    for (int p = sl; p < np; p += LPF) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
+    for (int off = LPF >> 1; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
+  }
   // ---- c0 = S^H Y
   if constexpr (CM > 0) {
     static_assert(CM == 2048, "one 256-thread workgroup = one 2048-point transform");
     cx<T>* fl = (cx<T>*)(smem + lay.off_fft);
+    if (lay.reg_c0) __syncthreads();             // every wavefront has its ||Y||^2: the rows may be overwritten
     for (int fi2 = 0; fi2 < FB; ++fi2) {
       cx<T> v[8];
 #pragma unroll
@@ -157,41 +186,44 @@ __global__ __launch_bounds__(256) void omp_batch_kernel(FastParams<T> P, OmpLayo
         const int i = tid + e * (CM / 8);
         v[e] = i < np ? conj(Yl[fi2 * YS + i]) : mk<T>(0, 0);
       }
-      wg_fft<T, CM, false>(v, tid, tw_m, fl);                 // c0 = conj(FFT(conj(Y)))
+      wg_fft<T, CM, false>(v, tid, tw_m, fl);                 // c0 = conj(FFT(conj(Y)))  (its first barrier follows the loads above)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = tid + e * (CM / 8);
-        if (k < K) c0[fi2 * K + k] = conj(v[e]);
+        if (k < K) c0[fi2 * CS + k] = conj(v[e]);
       }
     }
   } else if constexpr (MFMA) {
-    corr_mfma_f32(P.sct, K, K / 16, Yl, YS, np, FB, (float*)c0, K, wave, lane);
+    corr_mfma_f32(P.sct, K, K / 16, Yl, YS, np, FB, (float*)c0, CS, wave, lane);
   } else {
     for (int i = tid; i < FB * K; i += 256) {
       const int f = i / K, k = i - f * K;
       cx<T> acc = mk<T>(0, 0);
       for (int p = 0; p < np; ++p) acc = acc + P.sct[(size_t)p * K + k] * Yl[f * YS + p];
-      c0[i] = acc;
+      c0[f * CS + k] = acc;
     }
   }
   __syncthreads();
-  // ---- stage 2: FPW frames per wavefront side by side (no workgroup barrier below)
-  const int LPF = 64 / FPW;                      // lanes per frame
-  const int grp = lane / LPF, sl = lane - grp * LPF;
-  const int fi = wave * FPW + grp;               // frame slot inside the workgroup
+  // ---- stage 2: FPW frames per wavefront side by side (no workgroup barrier below, but for the hand-over of the reg_c0 layout)
   const int64_t f = f0 + fi;
   const bool live = f < n_frames;
-  const cx<T>* yf = Yl + fi * YS;
-  const cx<T>* cf = c0 + fi * K;
-  double ynorm = 0;
-  for (int p = sl; p < np; p += LPF) ynorm += (double)yf[p].x * yf[p].x + (double)yf[p].y * yf[p].y;
-  for (int off = LPF >> 1; off > 0; off >>= 1) ynorm += __shfl_xor(ynorm, off, 64);
+  const cx<T>* cf = c0 + fi * CS;
   if (taps <= OMP_RT) {
     omp_frame_reg<T>(P, cf, gl, K, taps, LPF, sl, live, ynorm, f);
   } else {
     // one frame per wavefront (lay.fpw == 1): picks / coefficients in lanes, R = L^-1 in LDS (omp_wave_core.hpp)
     cx<T>* Rm = (cx<T>*)(smem + lay.off_state + (size_t)fi * lay.state_bytes);
-    omp_frame_wave<T>(P, cf, gl, Rm, K, taps, live, ynorm, f);
+    cx<T> c0r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c0r[u] = mk<T>(0, 0);
+    if (lay.reg_c0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c0r[u] = lane + 64 * u < K ? cf[lane + 64 * u] : mk<T>(0, 0);
+      __syncthreads();                           // every wavefront holds its c0: the R states may take the bytes
+      omp_frame_wave<T, true>(P, cf, c0r, gl, Rm, K, taps, live, ynorm, f);
+    } else {
+      omp_frame_wave<T, false>(P, cf, c0r, gl, Rm, K, taps, live, ynorm, f);
+    }
   }
 }
 

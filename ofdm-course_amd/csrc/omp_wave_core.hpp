@@ -40,8 +40,10 @@ __device__ __forceinline__ double wave_sum(double v, int) {
 __host__ __device__ constexpr int omp_wave_rs(int taps) { return taps | 1; }          // odd row stride of R
 
 // cf = c0 of the frame [K], g2 = two-sided Gram table [KP + K] (index d + KP, KP = K rounded up to 512), Rm = this wavefront's R [taps][omp_wave_rs(taps)]
-template <typename T>
-__device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<T>* __restrict__ cf,
+// C0REG: c0 of the frame sits in registers (c0r[u] = c0[lane + 64 u], K <= 512; cf is not read) -- the LDS it came from is
+// then free for the R states (omp_layout, reg_c0)
+template <typename T, bool C0REG = false>
+__device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<T>* __restrict__ cf, const cx<T> (&c0r)[8],
                                                const cx<T>* __restrict__ g2, cx<T>* __restrict__ Rm, int K, int taps,
                                                bool live, double ynorm, int64_t f) {
   const int lane = threadIdx.x & 63;
@@ -65,7 +67,10 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
     for (int kb = lane; kb < K; kb += 8 * 64) {
       cx<T> c[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c[u] = kb + 64 * u < K ? cf[kb + 64 * u] : mk<T>(0, 0);
+      for (int u = 0; u < 8; ++u) {
+        if constexpr (C0REG) c[u] = c0r[u];                  // (one pass: K <= 512)
+        else c[u] = kb + 64 * u < K ? cf[kb + 64 * u] : mk<T>(0, 0);
+      }
       // g2[KP + pq - k], k = kb + 64 u: one address per pick (the pick is wave-uniform), eight reads at immediate offsets.
       // The table is KP + K long (KP = K rounded up to 512), so the atoms past the end of the dictionary read in bounds;
       // their scores are never looked at.
@@ -138,7 +143,16 @@ __device__ __forceinline__ void omp_frame_wave(const FastParams<T>& P, const cx<
     const cx<T> lzp = l * zq;                    // zq = 0 in lanes >= n
     const cx<T> lz = mk<T>(wave_sum(lane < n ? lzp.x : T(0), lane), wave_sum(lane < n ? lzp.y : T(0), lane));
     const T inv = T(1) / sqrt(g0 - nrm);
-    const cx<T> zn = (cf[kp] - lz) * inv;        // b_n = a_n^H y = c0[kp]
+    cx<T> bn;                                    // b_n = a_n^H y = c0[kp]
+    if constexpr (C0REG) {
+      cx<T> pick = c0r[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) pick = (kp >> 6) == u ? c0r[u] : pick;       // kp is wave-uniform
+      bn = lane_bcast(pick, kp & 63);
+    } else {
+      bn = cf[kp];
+    }
+    const cx<T> zn = (bn - lz) * inv;
     // ---- R(n, j) = -(1/lambda) sum_{k>=j} l_k R(k, j);  x_j += conj(R(n, j)) z_n (j < n);  x_n = z_n / lambda
     cx<T> r = mk<T>(0, 0);
     for (int k = 0; k < ns; ++k) {

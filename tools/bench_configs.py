@@ -196,7 +196,7 @@ def c4():
 
 def c5():
     cfg = fr.config_C5()
-    F = 2048
+    F = 3072       # a multiple of 3 x 256 CUs x 4 frames: the 32-tap pursuit keeps three four-frame workgroups per CU resident
     data = fr.make_frames(cfg, ofdm, F, seed=5, precision="fp32", device=dev)
     plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
     ref = torch.from_numpy(data["packed"]).to(dev)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ofdm_course_amd as ofdm
 from ofdm_course_amd import frames as fr
-F = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ofdm.init(0)
 dev = torch.device("cuda:0")

@@ -21,9 +21,9 @@ step clock
 bash tools/clock_probe.sh $out/clock > $out/clock_probe.txt 2>&1
 export C5_WARM_S=0.5
 step c5
-timeout -k 10 300 python tools/c5_run.py 2048 20 > $out/c5.txt 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5_stats -- python tools/c5_run.py 2048 20 > /dev/null 2>&1 && cp $out/c5_stats/*/*kernel_stats.csv $out/c5_kernel_stats.csv
-C5_WARM_S=0.02 bash tools/pmc_cmd.sh $out/c5_pmc python tools/c5_run.py 2048 5 > $out/c5_pmc_summary.txt 2>&1
+timeout -k 10 300 python tools/c5_run.py 3072 20 > $out/c5.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5_stats -- python tools/c5_run.py 3072 20 > /dev/null 2>&1 && cp $out/c5_stats/*/*kernel_stats.csv $out/c5_kernel_stats.csv
+C5_WARM_S=0.02 bash tools/pmc_cmd.sh $out/c5_pmc python tools/c5_run.py 3072 5 > $out/c5_pmc_summary.txt 2>&1
 timeout -k 10 300 python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 2 --frames-per-tile 64 --json $out/sweep_c5.json > /dev/null 2>&1
 step c3
 timeout -k 10 300 python tools/c3_run.py 4096 10 > $out/c3.txt 2>&1
