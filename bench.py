@@ -111,7 +111,29 @@ def host_threads():
     return n
 
 
+# Work-skipping ablation switches of rounds 1-2: gone from the shipped library (only the -DOFDM_DIAG build of tools/ has
+# OFDM_WAVE_ABL); a benchmark must not be able to skip work by environment, so their mere presence is refused.
+RESULT_CHANGING_ENV = ("OFDM_WAVE_ABL", "OFDM_CHAIN_SKIP")
+
+
+def env_in_force():
+    """Every OFDM_* variable set for this run (the library's path-selection switches)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("OFDM_")}
+
+
+def refuse_result_changing_env():
+    bad = [k for k in RESULT_CHANGING_ENV if k in os.environ]
+    if bad and not os.environ.get("OFDM_BENCH_ALLOW_DIAG"):
+        print(f"bench.py: refusing to run with work-skipping diagnostic variable(s) set: {bad} "
+              "(they change results; unset them)", file=sys.stderr)
+        sys.exit(3)
+    if bad and "_diag" not in os.environ.get("OFDM_LIB_PATH", ""):
+        print(f"bench.py: {bad} only exist in libofdm_mi355x_diag.so (OFDM_LIB_PATH)", file=sys.stderr)
+        sys.exit(3)
+
+
 def main():
+    refuse_result_changing_env()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000, help="timed steps (2000 x 0.45 ms = 0.9 s of GPU time)")
@@ -273,6 +295,7 @@ def main():
                                    f" (all launches of one step; dominant: {sym_kernel})",
                          "kernel_ms": kernel_ms, "bytes_per_symbol": b_sym},
             "kernels_ms": dict(zip(knames, kvals)),
+            "env": env_in_force(),
         }
         # HBM bytes per step from the committed PMC passes (cannot be collected from inside this process): only
         # quoted when this run is the workload those passes profiled

@@ -38,13 +38,13 @@ def _digest(paths, extra=""):
     return h.hexdigest()
 
 
-def _compile(src, hdr_digest, verbose):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src, hdr_digest, verbose, extra=()):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ("_diag" if extra else "") + ".o")
     stamp = obj + ".sha"
-    want = _digest([src], hdr_digest + " ".join(CFLAGS))
+    want = _digest([src], hdr_digest + " ".join([*CFLAGS, *extra]))
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj, False
-    cmd = [HIPCC, *CFLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *CFLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -57,26 +57,30 @@ def _compile(src, hdr_digest, verbose):
     return obj, True
 
 
-def build_library(verbose: bool = False, force: bool = False) -> str:
+def build_library(verbose: bool = False, force: bool = False, diag: bool = False) -> str:
+    """diag=True builds libofdm_mi355x_diag.so with -DOFDM_DIAG: the work-skipping ablation switches of tools/ (never
+    loaded by the package, bench.py or the tests; the shipped library does not contain them)."""
     os.makedirs(OBJ, exist_ok=True)
+    extra = ("-DOFDM_DIAG",) if diag else ()
+    lib = LIB[:-3] + "_diag.so" if diag else LIB
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     hdr = _digest(_headers())
     srcs = _sources()
     with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, hdr, verbose), srcs))
+        res = list(ex.map(lambda s: _compile(s, hdr, verbose, extra), srcs))
     objs = [o for o, _ in res]
     changed = any(c for _, c in res)
-    if changed or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    if changed or not os.path.exists(lib):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(verbose=True, force="--force" in sys.argv))
+    print(build_library(verbose=True, force="--force" in sys.argv, diag="--diag" in sys.argv))

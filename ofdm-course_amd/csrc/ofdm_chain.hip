@@ -38,7 +38,6 @@ struct ChainParams {
   const cx<T>* tw;           // [nfft] exp(-2 pi i m / nfft)
   DemapTable<T> tab;
   int frame_words;           // packed 32-bit words per frame
-  int dbg_skip;              // diagnostic only (env OFDM_CHAIN_SKIP): 1 c0, 2 OMP loop, 4 demap, 8 pack, 16 FFT of symbols >1
   // byte offsets of the per-group LDS pieces (computed once on the host)
   unsigned off_y, off_c0, off_xs, off_picks, off_gram, off_codes, group_bytes;
 };
@@ -157,13 +156,12 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
   ynorm = group_sum<TPX>(ynorm, sh_sum);
   for (int k = j; k < P.k_atoms; k += TPX) {
     cx<T> acc = mk<T>(0, 0);
-    if (!(P.dbg_skip & 1))
-      for (int p = 0; p < P.np; ++p) acc = acc + P.sct[(size_t)p * P.k_atoms + k] * Y[p];
+    for (int p = 0; p < P.np; ++p) acc = acc + P.sct[(size_t)p * P.k_atoms + k] * Y[p];
     c0[k] = acc;
   }
   __syncthreads();
   double rho_prev = ynorm;
-  for (int it = 0; it < ((P.dbg_skip & 2) ? 0 : P.taps); ++it) {
+  for (int it = 0; it < P.taps; ++it) {
     const int n_prev = ctl[0];
     const bool active = (ctl[1] == 0);
     // residual correlation c = c0 - G(:,index) x  and its arg-max (OMP_estimate.m:7,:14)
@@ -282,14 +280,14 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
       const cx<T>* src = frx + (int64_t)s * L + P.t_guard;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = live ? src[j + e * TPX] : mk<T>(0, 0);
-      if (!(P.dbg_skip & 16)) wg_fft<T, N, false>(v, j, P.tw, lfft);
+      wg_fft<T, N, false>(v, j, P.tw, lfft);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = j + e * TPX;
       if (k < P.n_carrier) {
         const int d = P.drole[k];
-        if (d >= 0) codes[s * P.nd + d] = (P.dbg_skip & 4) ? (uint8_t)(v[e].x > 0) : (uint8_t)demap_decide(P.tab, v[e] * geq[e]);
+        if (d >= 0) codes[s * P.nd + d] = (uint8_t)demap_decide(P.tab, v[e] * geq[e]);
       }
     }
   }
@@ -298,7 +296,7 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
   // ================= pack bits (MSB-first inside each byte) + BER numerator =======================
   const int64_t frame_bits = (int64_t)P.nd * P.n_symb * bps;
   unsigned int err = 0;
-  for (int w = j; w < ((P.dbg_skip & 8) ? 0 : P.frame_words); w += TPX) {
+  for (int w = j; w < P.frame_words; w += TPX) {
     uint32_t word = 0;
     const int64_t b0 = (int64_t)w * 32;
     for (int b = 0; b < 32; ++b) {
@@ -361,7 +359,6 @@ static int launch_chain(const ofdm_rx_plan* pl, const void* tw, const void* rx, 
   P.pc0 = (const int32_t*)pl->d_pc0; P.tw = (const cx<T>*)tw;
   fill_demap_table<T>(pl->dict, pl->cinfo, P.tab);
   P.frame_words = pl->frame_words;
-  { const char* e = getenv("OFDM_CHAIN_SKIP"); P.dbg_skip = e ? atoi(e) : 0; }
   constexpr int FPW = fft_xforms_per_wg(N);
   chain_layout<T>(P, N, pl->bps);
   const size_t dyn = (size_t)P.group_bytes * FPW;

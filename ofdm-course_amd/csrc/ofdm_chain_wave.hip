@@ -424,8 +424,10 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
     switch (ba) {
       case 2: WAVE_CASE(2, false); break;
       case 3:
-        if (getenv("OFDM_WAVE_ABL")) OFDM_TRY(launch(rx_symbols_wave_kernel<3, false, 4, 1>));   // diagnostic: no sample stream
-        else { WAVE_CASE(3, false); }
+#ifdef OFDM_DIAG   // tools-only build (libofdm_mi355x_diag.so, build.py --diag): issue time without the sample stream
+        if (getenv("OFDM_WAVE_ABL")) { OFDM_TRY(launch(rx_symbols_wave_kernel<3, false, 4, 1>)); break; }
+#endif
+        WAVE_CASE(3, false);
         break;
       case 4: WAVE_CASE(4, false); break;
       default: WAVE_CASE(0, false); break;

@@ -60,6 +60,20 @@ def test_product_code_never_imports_the_oracle():
                     assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, fn)
 
 
+def test_shipped_library_has_no_work_skipping_switches():
+    """the ablation switches that skip work (OFDM_WAVE_ABL, OFDM_CHAIN_SKIP) are not in the product
+    library (the former lives in the -DOFDM_DIAG build of tools/ only), and bench.py refuses to run with one set."""
+    import subprocess
+    import sys
+    blob = open(os.path.join(ROOT, "ofdm-course_amd", "libofdm_mi355x.so"), "rb").read()
+    for name in (b"OFDM_WAVE_ABL", b"OFDM_CHAIN_SKIP"):
+        assert blob.count(name) == 0, name
+    for var in ("OFDM_WAVE_ABL", "OFDM_CHAIN_SKIP"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True,
+                           env=dict(os.environ, **{var: "1"}))
+        assert r.returncode != 0 and var in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-300:])
+
+
 def test_bit_packing_roundtrip_and_layout():
     from ofdm_course_amd import frames as fr
     rng = np.random.default_rng(0)

@@ -1,8 +1,10 @@
 # usage: tools/clock_probe.sh <outdir> ; effective shader clock (GRBM_GUI_ACTIVE / 8 / duration) of the symbol kernel with and
-# without its sample stream (OFDM_WAVE_ABL=1 = diagnostic build that issues no sample loads in the symbol loop)
-out=$1; mkdir -p $out; root=$PWD; cd /tmp && export TMPDIR=/tmp && cd $root
+# without its sample stream (OFDM_WAVE_ABL=1 on libofdm_mi355x_diag.so = -DOFDM_DIAG build that issues no sample loads in the symbol loop; the shipped
+# library has no such switch)
+out=$1; mkdir -p $out; root=$PWD; python ofdm-course_amd/build.py --diag > $out/diag_build.log 2>&1
+ cd /tmp && export TMPDIR=/tmp && cd $root
 for v in normal abl; do
-  if [ $v = abl ]; then export OFDM_WAVE_ABL=1; else unset OFDM_WAVE_ABL; fi
+  if [ $v = abl ]; then export OFDM_WAVE_ABL=1 OFDM_BENCH_ALLOW_DIAG=1 OFDM_LIB_PATH=$root/ofdm-course_amd/libofdm_mi355x_diag.so; else unset OFDM_WAVE_ABL OFDM_BENCH_ALLOW_DIAG OFDM_LIB_PATH; fi
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/$v -- python bench.py --no-cpu --steps 200 --warmup 20 > $out/$v.log 2>&1 || echo "pass $v failed"
 done
 python - <<PY
