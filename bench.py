@@ -111,6 +111,62 @@ def host_threads():
     return n
 
 
+def f64_leg(ofdm, fr, cfg, dev, dev_index, F, steps, bps, check_frames):
+    """Config M in the reference's own arithmetic (MATLAB computes in double: T5/OFDM_demodulator.m:5-8, T5/OMP_estimate.m:9):
+    the same chain call on a float64 plan over F resident float64 frames (the wave-per-frame kernel is fp32 only, so the
+    symbol stage is the four-wavefront rx_symbols_kernel<double>).  Roofline on SURVEY 8(d)'s fp64 figure (37 586 B/symbol).
+    The frames come from the device generator in the reference's order (Noise -> conv); `check_frames` of them are decoded by
+    the oracle's C twin as well (identical error counts are required of parity mode)."""
+    import torch
+    plan = fr.make_plan(cfg, ofdm, precision="fp64", device=dev_index)
+    data = fr.make_frames_device(cfg, ofdm, plan, F, seed=1, device=dev, noise_first=True, want_bits=check_frames > 0)
+    rx, ref = data["rx"], data["packed"]
+    for _ in range(10):
+        out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
+    torch.cuda.synchronize()
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    t0 = time.perf_counter()
+    ev[0].record()
+    for _ in range(steps):
+        out = ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
+    ev[1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev[0].elapsed_time(ev[1]) / steps
+    plan.set_timing(True)
+    kms = []
+    for _ in range(5):
+        ofdm.rx_chain_task5(plan, rx, ref_bits_packed=ref)
+        kms.append(plan.last_kernel_ms())
+    plan.set_timing(False)
+    kms = np.mean(np.array(kms), axis=0)
+    nsym = F * cfg.N_symb
+    b_sym = algorithmic_bytes_per_symbol(cfg, bps, 16)
+    achieved = b_sym * nsym / (kernel_ms * 1e-3) / 1e9
+    names = ["rx_pilot_omp_kernel<double>", "omp_batch_kernel<double>", "rx_symbols_kernel<double>"]
+    r = {"value": nsym * steps / elapsed, "unit": "OFDM symbols/s", "dtype": "f64", "steps": steps, "frames_per_gpu": F,
+         "ms_per_step": elapsed / steps * 1e3,
+         "kernels_ms": {n: float(k) for n, k in zip(names, kms) if float(k) > 0.0},
+         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                      "kernel_ms": kernel_ms, "bytes_per_symbol": b_sym},
+         "ber": float(out["errors"].sum().item()) / (F * plan.frame_bits)}
+    if check_frames > 0:
+        from oracle import ofdm_oracle as oracle
+        from oracle import ofdm_oracle_c as oracle_c
+        n = min(check_frames, F)
+        D, _ = oracle.constellation_func(cfg.Constellation)
+        rx_host = np.ascontiguousarray(rx.t()[:n].contiguous().cpu().numpy())
+        want = oracle_c.rx_chain_task5(rx_host, cfg.Nfft, cfg.T_guard, cfg.N_carrier, cfg.pilotCarriers, cfg.dataCarriers,
+                                       fr.pilot_column(cfg, ofdm), cfg.K, cfg.dominant_taps, D,
+                                       ref_bits=data["bits"][:n].cpu().numpy(), n_threads=max(1, min(host_threads(), n // 4)),
+                                       frame_major=True)
+        got = out["errors"][:n].cpu().numpy().astype(np.int64)
+        r["ber_match"] = {"frames": int(n), "gpu_errors": int(got.sum()), "oracle_errors": int(want["errors"].sum()),
+                          "max_abs_diff_per_frame": int(np.max(np.abs(got - want["errors"])))}
+    plan.close()
+    return r
+
+
 # Work-skipping ablation switches of rounds 1-2: gone from the shipped library (only the -DOFDM_DIAG build of tools/ has
 # OFDM_WAVE_ABL); a benchmark must not be able to skip work by environment, so their mere presence is refused.
 RESULT_CHANGING_ENV = ("OFDM_WAVE_ABL", "OFDM_CHAIN_SKIP")
@@ -148,6 +204,9 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=0.3, help="untimed settling time before the W warm-up steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this GPU")
+    ap.add_argument("--no-f64", action="store_true", help="skip the reference-precision (float64) leg of config M")
+    ap.add_argument("--f64-steps", type=int, default=150)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2..C5 lines")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,7 +238,9 @@ def main():
     _, bps = ofdm.constellation_func(cfg.Constellation)
     F = args.frames
     f0 = rank * F
-    data = fr.make_frames(cfg, ofdm, F, seed=1, precision=args.precision, device=dev, frame0=f0)
+    # channel stages in the order of the reference's drivers: Noise(20 dB) on the TX signal, then conv(h)
+    # (T5/Main_model_Task_5.m:106-127, T5/Task5_part2.m:134,:152) -- rounds 1-2 benchmarked conv -> Noise frames
+    data = fr.make_frames(cfg, ofdm, F, seed=1, precision=args.precision, device=dev, frame0=f0, noise_first=True)
     plan = fr.make_plan(cfg, ofdm, precision=args.precision, device=dev_index)
     ref = torch.from_numpy(data["packed"]).to(dev)
     rx = data["rx"]
@@ -284,7 +345,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
             "config": {"workload": "M: Nfft=2048 Tg=256 N_carrier=512 comb=4 (128 pilots, K=128) 64QAM OMP(6 taps) "
-                                   "6-tap channel 20 dB, frames of 14 symbols",
+                                   "Noise(20 dB) -> 6-tap channel (the reference's order), frames of 14 symbols",
                        "frames_per_gpu": F, "symbols_per_step": sym_per_step, "sharding": f"frames x{world}"},
             "ber": tot_err / max(tot_bits, 1),
             "frame_errors": {"frames": int(ferr.size), "sum": int(ferr.sum()),
@@ -340,6 +401,15 @@ def main():
             res["ber_match"] = {"frames": int(ncpu), "gpu_errors": int(gpu_errs.sum()),
                                 "oracle_errors": int(cb["errors"].sum()),
                                 "max_abs_diff_per_frame": int(np.max(np.abs(gpu_errs - cb["errors"])))}
+        if world == 1 and not args.no_f64 and args.precision == "fp32":
+            del data, rx, ref, out, plan
+            torch.cuda.empty_cache()
+            res["f64"] = f64_leg(ofdm, fr, cfg, dev, dev_index, F, args.f64_steps, bps, 0 if args.no_cpu else 256)
+        if world == 1 and not args.no_secondary:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            res["secondary"] = bench_configs.secondary_all()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -117,6 +117,11 @@ int ofdm_Noise_frames(double snr_db, const void* x, int64_t frame_len, int64_t n
 /* T5/add_STO.m:1-10 and T5/add_CFO.m:1-8. */
 int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags);
 int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, int flags);
+/* add_STO then add_CFO of a batch of frames y[frame_len x n_frames], frame f with its own n_sto[f] (int64) and cfo[f]
+ * (double) -- the per-run draws of T4/Main_model_Task_4.m:101-110; either array may be NULL (stage off).  The arrays
+ * live where `flags` says. */
+int ofdm_add_STO_CFO_frames(const void* y, int64_t frame_len, int64_t n_frames, const int64_t* n_sto, const double* cfo,
+                            int nfft, void* out, int flags);
 
 /* ---- synchronisation --------------------------------------------------------------------- */
 /* T5/AutoCorrFunction.m:1-28.  rho_out[len-width-nfft] complex (may be NULL);
@@ -211,8 +216,9 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* plan, const void* h, int64_t n_h, double
  *   OFDM_demodulator; fine_sync (Task-4 variant) if either flag                                      (:310-314)
  *   if mp_desync:                   estimate_channel + equalize_signal                               (:318-334)
  *   get_payload; demapping                                                                           (:340-347)
- * bits_out: packed demapped bits per frame (layout of ofdm_rx_chain_task5; the per-frame DeScrambler of :354-364 is
- * the caller's, ofdm_DeScrambler_frames); errors_out: differences to ref_bits (pass the scrambled bits).
+ * bits_out: packed demapped bits per frame (layout of ofdm_rx_chain_task5), after the per-frame DeScrambler of :354-364
+ * when the plan has one (ofdm_rx_plan_set_descrambler); errors_out: differences to ref_bits (the scrambled bits without
+ * a descrambler, the payload bits with it).
  * tg_position_out / freq_offset_out / ifo_out: the per-frame estimates (0 where a stage is off);
  * status_out: 0 ok, 1 = AutoCorrFunction's catch branch (TgPosition 65, :19-24), -1 = remove_IFO found no line above
  * 0.77 (the script would abort at remove_IFO.m:8; the frame is decoded with IFO = 0), -2 = TgPosition beyond AutoCorr.
@@ -220,15 +226,38 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* plan, const void* h, int64_t n_h, double
 int ofdm_rx_chain_task4(ofdm_rx_plan* plan, const void* rx, int64_t n_frames, int time_desync, int freq_desync, int mp_desync,
                         uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out, int64_t* tg_position_out,
                         double* freq_offset_out, int32_t* ifo_out, int32_t* status_out, void* h_out, int flags);
-/* Synthetic RX frames of the plan's geometry, generated on the device (no host payload): per frame the TX + channel
- * call order of T5/Main_model_Task_5.m:50-127 -- payload (one Philox4x32-10 draw per QAM symbol, stream = frame0 + f)
- * -> mapping (T5/mapping.m) -> OFDM_map_carriers with the plan's pilot column on every symbol -> OFDM_modulator ->
- * conv(x, h) truncated per frame (:126-127; h = host array of h_len complex taps in the precision of `flags`, NULL =
- * no channel) -> Noise(snr_db) per frame (noise_on != 0).  rx_out: [frame_samples x n_frames]; ref_bits_out: packed
- * payload bits [n_frames][frame_bytes] in the layout ofdm_rx_chain_task5 compares against; bits_out (optional): one
- * byte per bit [n_frames][frame_bits].  Results depend on (seed, frame0 + f) only, not on how frames are batched. */
+/* Synthetic RX frames of the plan's geometry, generated on the device (no host payload), per frame:
+ *   payload (one Philox4x32-10 draw per QAM symbol, stream = frame0 + f)
+ *   -> Scrambler with the register reset per frame (T5/Main_model_Task_5.m:55-69; scr_reg15 = HOST uint8[15], NULL = off)
+ *   -> mapping (T5/mapping.m) -> OFDM_map_carriers with the plan's pilot column on every symbol -> OFDM_modulator
+ *   -> channel stages.  noise_first != 0 is the REFERENCE order (T5/Main_model_Task_5.m:106-127, T4/Main_model_Task_4.m:
+ *      94-110,:257-267, T5/Task5_part2.m:134,:152):  Noise(snr_db) -> add_STO -> add_CFO -> conv(x, h) truncated per frame;
+ *      noise_first == 0 (the order ofdm_tx_frames has always used):  add_STO -> add_CFO -> conv -> Noise, i.e. the SNR is
+ *      set on the channel's output.  h = host array of h_len complex taps in the precision of `flags`, NULL = no channel;
+ *      noise_on == 0 = no Noise stage.
+ *   STO / CFO per frame (T4/Main_model_Task_4.m:101-110): mode 0 = off, 1 = sto_value / cfo_value for every frame,
+ *      2 = drawn per frame from Philox counter (0, 0, frame0 + f, 2): Time_Delay = word0 mod (Nfft + T_guard + 1)
+ *      [randi([0, Nfft+T_Guard])], Freq_Shift = (word1 mod 31) + ((word2 + 0.5) 2^-32 - 0.5) [randi([0,30]) + (rand-0.5)].
+ * rx_out: [frame_samples x n_frames]; ref_bits_out: the packed PAYLOAD (input) bits [n_frames][frame_bytes] in the layout
+ * ofdm_rx_chain_task5 compares against (with the Scrambler on, compare after ofdm_rx_plan_set_descrambler);
+ * bits_out (optional): the payload, one byte per bit [n_frames][frame_bits]; sc_ref_bits_out (optional, Scrambler on): the
+ * packed SCRAMBLED bits, what the demapper decides; sto_out / cfo_out (optional): the per-frame draws (int64 / double).
+ * All outputs live where `flags` says.  Results depend on (seed, frame0 + f) only, not on how frames are batched. */
+int ofdm_tx_frames_ex(ofdm_rx_plan* plan, const void* h, int h_len, double snr_db, int noise_on, uint64_t seed,
+                      int64_t frame0, int64_t n_frames, const uint8_t* scr_reg15, int sto_mode, int64_t sto_value,
+                      int cfo_mode, double cfo_value, int noise_first, void* rx_out, uint8_t* ref_bits_out,
+                      uint8_t* bits_out, uint8_t* sc_ref_bits_out, int64_t* sto_out, double* cfo_out, int flags);
+/* = ofdm_tx_frames_ex without Scrambler / STO / CFO and with noise_first = 0 (conv -> Noise; NOT the order of the
+ * reference's drivers, which add the noise before the channel -- use ofdm_tx_frames_ex(noise_first = 1) for that). */
 int ofdm_tx_frames(ofdm_rx_plan* plan, const void* h, int h_len, double snr_db, int noise_on, uint64_t seed,
                    int64_t frame0, int64_t n_frames, void* rx_out, uint8_t* ref_bits_out, uint8_t* bits_out, int flags);
+/* Per-frame DeScrambler inside ofdm_rx_chain_task5 / ofdm_rx_chain_task4 (T5/DeScrambler.m:1-16 with
+ * the register reset for every frame, T5/Main_model_Task_5.m:257-274, T4/Main_model_Task_4.m:354-364): the demapped bits
+ * of a frame go through d[i] = s[i] ^ s[i-13] ^ s[i-14], s[-m] = reg15[m-1], before they are written to bits_out and
+ * compared with ref_bits (which then hold the TX's INPUT bits): inside the pack stage of the wave-per-frame symbol kernel
+ * (the metric geometry), as one more pass over the packed words on every other path.  ofdm_task5_part2_tile refuses a plan
+ * with a DeScrambler (the study runs unscrambled, T5/Task5_part2.m:104-114).  reg15: HOST uint8[15]; NULL = off. */
+int ofdm_rx_plan_set_descrambler(ofdm_rx_plan* plan, const uint8_t* reg15);
 int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes per frame (4-byte multiple) */
 /* One tile of the Monte-Carlo study of T5/Task5_part2.m:148-205, :269-304: n_frames channel realisations jj of the plan's
  * pilot scenario kk, all four estimators on every realisation, nothing but sums returned.
@@ -252,6 +281,10 @@ int ofdm_task5_part2_tile(ofdm_rx_plan* plan, const void* tx_noised, const int32
  * kernel}; the generic single-kernel path reports {0, 0, total}). */
 int ofdm_rx_plan_set_timing(ofdm_rx_plan* plan, int enable);
 int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* plan, float* ms3);
+/* The same for ofdm_rx_chain_task4: ms5 = {AutoCorrFunction stage, remove_IFO stage, OFDM_demodulator, fine_sync +
+ * estimate_channel, equalise + demap (+ DeScrambler)} of the last call (T4/Main_model_Task_4.m:278, :301-303, :308-310,
+ * :313-318, :334-364). */
+int ofdm_rx_plan_last_task4_ms(ofdm_rx_plan* plan, float* ms5);
 int ofdm_rx_chain_task5(ofdm_rx_plan* plan, const void* rx, int64_t n_frames,
                         uint8_t* bits_out, const uint8_t* ref_bits, uint32_t* errors_out,
                         void* h_out, int32_t* index_out, int flags);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ofdm_Noise_frames": [_d, _vp, _i64, _i64, C.c_uint64, C.c_uint32, _vp, _i],
     "ofdm_add_STO": [_vp, _i64, _i64, _vp, _i],
     "ofdm_add_CFO": [_vp, _i64, _d, _i, _vp, _i],
+    "ofdm_add_STO_CFO_frames": [_vp, _i64, _i64, _vp, _vp, _i, _vp, _i],
     "ofdm_AutoCorrFunction": [_vp, _i64, _i, _i, _vp, _pi64, _pd, _i],
     "ofdm_remove_IFO": [_vp, _i64, _i, _vp, _pi, _i],
     "ofdm_fine_sync": [_vp, _i, _i64, _vp, _i, _vp, _i, _i, _i, _vp, _pd, _pd, _i],
@@ -70,9 +71,12 @@ SIGNATURES = {
     "ofdm_rx_plan_set_mmse": [_vp, _vp, _i64, _d, _i],
     "ofdm_rx_chain_task4": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ofdm_tx_frames": [_vp, _vp, _i, _d, _i, C.c_uint64, _i64, _i64, _vp, _vp, _vp, _i],
+    "ofdm_tx_frames_ex": [_vp, _vp, _i, _d, _i, C.c_uint64, _i64, _i64, _vp, _i, _i64, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ofdm_rx_plan_set_descrambler": [_vp, _vp],
     "ofdm_rx_plan_frame_bytes": [_vp],
     "ofdm_rx_plan_set_timing": [_vp, _i],
     "ofdm_rx_plan_last_kernel_ms": [_vp, C.POINTER(C.c_float)],
+    "ofdm_rx_plan_last_task4_ms": [_vp, C.POINTER(C.c_float)],
     "ofdm_rx_chain_task5": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i],
     "ofdm_task5_part2_tile": [_vp, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp, _i],
 }

@@ -33,7 +33,7 @@ __all__ = [
     "OfdmError", "init", "shutdown", "constellation_func", "mapping", "demapping", "Scrambler",
     "DeScrambler", "Scrambler_frames", "DeScrambler_frames", "OFDM_map_carriers", "get_payload",
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
-    "add_CFO", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
+    "add_CFO", "add_STO_CFO_frames", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
     "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "task5_part2_tile", "DEFAULT_REGISTER",
 ]
@@ -386,6 +386,22 @@ def add_STO(y, nSTO):
     return out
 
 
+def add_STO_CFO_frames(y, nSTO=None, CFO=None, Nfft=1):
+    """add_STO then add_CFO per frame of y [frame_len, n_frames] (column = frame), every frame with its own nSTO[f] / CFO[f]
+    (T4/Main_model_Task_4.m:101-110 per Monte-Carlo run); None leaves a stage out."""
+    call = _Call(y)
+    frame_len, n_frames = _shape2(y)
+    out, pout = call.cout((frame_len, n_frames))
+    ps = pc = None
+    if nSTO is not None:
+        ps = call._flat(nSTO, np.int64, torch.int64 if call.dev else None)[0]
+    if CFO is not None:
+        pc = call._flat(CFO, np.float64, torch.float64 if call.dev else None)[0]
+    L.check(call.lib.ofdm_add_STO_CFO_frames(call.cin(y), frame_len, n_frames, ps, pc, int(Nfft), pout, call.flags),
+            "add_STO_CFO_frames")
+    return out
+
+
 def add_CFO(y, CFO, Nfft):
     """T5/add_CFO.m:1-8."""
     call = _Call(y)
@@ -652,42 +668,86 @@ class RxPlan:
         L.check(self.lib.ofdm_rx_plan_set_mmse(self.handle, hh.ctypes.data_as(C.c_void_p), hh.size, float(SNR),
                                                L.OFDM_F64 | L.OFDM_HOST), "rx_plan_set_mmse")
 
-    def tx_frames(self, n_frames, h=None, SNR=None, seed=1, frame0=0, device=None, want_bits=False):
-        """Synthetic RX frames of this plan's geometry generated on the device (ofdm_tx_frames): payload -> mapping ->
-        OFDM_map_carriers -> OFDM_modulator -> conv(h) -> Noise(SNR), the TX + channel call order of
-        T5/Main_model_Task_5.m:50-127 per frame.  h=None: no channel; SNR=None: no noise.
-        Returns dict(rx=[frame_samples, n_frames], packed=[n_frames, frame_bytes] (+ bits=[n_frames, frame_bits]));
+    def set_descrambler(self, Register=None):
+        """Per-frame DeScrambler(Register, .) inside rx_chain_task5 / rx_chain_task4 (T5/Main_model_Task_5.m:257-274): the
+        demapped bits of every frame are descrambled in the pack stage before they are written / compared.  None = off."""
+        if Register is None:
+            L.check(self.lib.ofdm_rx_plan_set_descrambler(self.handle, None), "rx_plan_set_descrambler")
+            return
+        reg = np.ascontiguousarray(np.asarray(Register).ravel().astype(np.uint8))
+        if reg.size != 15:
+            raise OfdmError("set_descrambler: Register must have 15 entries")
+        L.check(self.lib.ofdm_rx_plan_set_descrambler(self.handle, reg.ctypes.data_as(C.c_void_p)), "rx_plan_set_descrambler")
+
+    def tx_frames(self, n_frames, h=None, SNR=None, seed=1, frame0=0, device=None, want_bits=False, Register=None,
+                  Time_Delay=None, Freq_Shift=None, noise_first=False, want_draws=False):
+        """Synthetic RX frames of this plan's geometry generated on the device (ofdm_tx_frames_ex): payload ->
+        [Scrambler(Register, .) per frame] -> mapping -> OFDM_map_carriers -> OFDM_modulator -> channel stages.
+        noise_first=True is the reference's order (T5/Main_model_Task_5.m:106-127, T4/Main_model_Task_4.m:94-110,:257-267):
+        Noise(SNR) -> add_STO -> add_CFO -> conv(h); the default (False) is add_STO -> add_CFO -> conv(h) -> Noise(SNR).
+        h=None: no channel; SNR=None: no noise.  Time_Delay / Freq_Shift: None = off, a number = that value for every
+        frame, "random" = the per-frame draw of T4/Main_model_Task_4.m:101-110.
+        Returns dict(rx=[frame_samples, n_frames], packed=[n_frames, frame_bytes] (the payload bits)
+        (+ bits=[n_frames, frame_bits]) (+ sc_packed = the scrambled bits when Register is given)
+        (+ Time_Delay [n_frames] int64, Freq_Shift [n_frames] float64 with want_draws));
         torch CUDA tensors when `device` is given, numpy arrays otherwise."""
         n_frames = int(n_frames)
         cdt_np = np.complex128 if self.f64 else np.complex64
         flags = (L.OFDM_F64 if self.f64 else L.OFDM_F32)
+        scr = Register is not None
         if device is not None:
             dev = torch.device(device)
             rx = torch.empty((n_frames, self.frame_samples), dtype=torch.complex128 if self.f64 else torch.complex64,
                              device=dev)
             packed = torch.empty((n_frames, self.frame_bytes), dtype=torch.uint8, device=dev)
             bits = torch.empty((n_frames, self.frame_bits), dtype=torch.uint8, device=dev) if want_bits else None
+            scp = torch.empty((n_frames, self.frame_bytes), dtype=torch.uint8, device=dev) if scr else None
+            sto = torch.empty((n_frames,), dtype=torch.int64, device=dev) if want_draws else None
+            cfo = torch.empty((n_frames,), dtype=torch.float64, device=dev) if want_draws else None
             L.check(self.lib.ofdm_set_stream(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "set_stream")
-            prx, ppk = C.c_void_p(rx.data_ptr()), C.c_void_p(packed.data_ptr())
-            pbt = C.c_void_p(bits.data_ptr()) if want_bits else None
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
             flags |= L.OFDM_DEVICE
         else:
             L.check(self.lib.ofdm_set_stream(None), "set_stream")
             rx = np.empty((n_frames, self.frame_samples), dtype=cdt_np)
             packed = np.empty((n_frames, self.frame_bytes), dtype=np.uint8)
             bits = np.empty((n_frames, self.frame_bits), dtype=np.uint8) if want_bits else None
-            prx, ppk = rx.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)
-            pbt = bits.ctypes.data_as(C.c_void_p) if want_bits else None
+            scp = np.empty((n_frames, self.frame_bytes), dtype=np.uint8) if scr else None
+            sto = np.empty((n_frames,), dtype=np.int64) if want_draws else None
+            cfo = np.empty((n_frames,), dtype=np.float64) if want_draws else None
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         hh = None
         if h is not None:
             hh = np.ascontiguousarray(np.asarray(h.cpu().numpy() if _is_torch(h) else h).ravel().astype(cdt_np))
-        L.check(self.lib.ofdm_tx_frames(self.handle, hh.ctypes.data_as(C.c_void_p) if hh is not None else None,
-                                        0 if hh is None else hh.size, float(SNR if SNR is not None else 0.0),
-                                        int(SNR is not None), int(seed), int(frame0), n_frames, prx, ppk, pbt, flags),
-                "tx_frames")
+        reg = None
+        if scr:
+            reg = np.ascontiguousarray(np.asarray(Register).ravel().astype(np.uint8))
+            if reg.size != 15:
+                raise OfdmError("tx_frames: Register must have 15 entries")
+
+        def mode(v):
+            if v is None:
+                return 0, 0
+            if isinstance(v, str):
+                if v != "random":
+                    raise OfdmError("tx_frames: Time_Delay / Freq_Shift must be None, a number or 'random'")
+                return 2, 0
+            return 1, v
+        sm, sv = mode(Time_Delay)
+        cm, cv = mode(Freq_Shift)
+        L.check(self.lib.ofdm_tx_frames_ex(self.handle, hh.ctypes.data_as(C.c_void_p) if hh is not None else None,
+                                           0 if hh is None else hh.size, float(SNR if SNR is not None else 0.0),
+                                           int(SNR is not None), int(seed), int(frame0), n_frames,
+                                           reg.ctypes.data_as(C.c_void_p) if scr else None, sm, int(sv), cm, float(cv),
+                                           int(bool(noise_first)), ptr(rx), ptr(packed), ptr(bits), ptr(scp), ptr(sto),
+                                           ptr(cfo), flags), "tx_frames")
         out = dict(rx=rx.t() if device is not None else rx.T, packed=packed)
         if want_bits:
             out["bits"] = bits
+        if scr:
+            out["sc_packed"] = scp
+        if want_draws:
+            out["Time_Delay"], out["Freq_Shift"] = sto, cfo
         return out
 
     def set_timing(self, enable=True):
@@ -698,6 +758,13 @@ class RxPlan:
         ms = (C.c_float * 3)()
         L.check(self.lib.ofdm_rx_plan_last_kernel_ms(self.handle, ms), "rx_plan_last_kernel_ms")
         return tuple(float(v) for v in ms)
+
+    def last_stage_ms(self):
+        """Stage milliseconds of the last rx_chain_task4 call (HIP events on the launch stream)."""
+        ms = (C.c_float * 5)()
+        L.check(self.lib.ofdm_rx_plan_last_task4_ms(self.handle, ms), "rx_plan_last_task4_ms")
+        return dict(zip(("AutoCorrFunction", "remove_IFO", "OFDM_demodulator", "fine_sync+estimate_channel", "equalize+demap"),
+                        (float(v) for v in ms)))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -215,6 +215,7 @@ struct FastParams {
   int32_t* tap_idx;          // [n_frames][taps]   0-based atom index, -1 = unused
   c64* tap_x;                // [n_frames][taps]
   const cx<T>* h_in;         // [n_frames][n_carrier] channel estimate made by another stage (MMSE mode), or nullptr
+  uint32_t descr;            // 0, or DESCR_ON | the DeScrambler register (bit m-1 = Register(m), m = 1..14): descramble per frame
 };
 
 
@@ -477,16 +478,44 @@ __device__ __forceinline__ int slice_symbol(const DemapTable<T>& tab, cx<T> z) {
   else return demap_square<T, BA>(tab, z);
 }
 
+// Per-frame DeScrambler of the fused receivers (T5/DeScrambler.m:8-13 with the register reset per frame,
+// T5/Main_model_Task_5.m:257-274): the register holds the last received bits, newest first, and the taps of array_xor pick
+// Register(13), Register(14), so  d[i] = s[i] ^ s[i-13] ^ s[i-14]  with  s[-m] = Register0(m).  On the packed stream (a word
+// in STREAM order = MSB first, i.e. before the byte swap of the little-endian store) that is two funnel shifts with the
+// previous word, of which only the low 14 bits matter.  `DESCR_ON` marks the mode, the low 14 bits carry s[-1] (bit 0) ..
+// s[-14] (bit 13) of the frame (or of the pack batch, for a kernel that packs a frame in several batches).
+constexpr uint32_t DESCR_ON = 0x80000000u;
+__device__ __forceinline__ uint32_t descr_word(uint32_t w, uint32_t prev) {
+  return w ^ ((w >> 13) | (prev << 19)) ^ ((w >> 14) | (prev << 18));
+}
+// the 14 stream bits that precede code index `idx` (a multiple of 16, >= 16): the tail of the 16 codes before it
+__device__ __forceinline__ uint32_t descr_tail(const uint8_t* __restrict__ codes, int idx, int bps) {
+  const uint4 pc = *reinterpret_cast<const uint4*>(codes + idx - 16);
+  const uint32_t cw[4] = {pc.x, pc.y, pc.z, pc.w};
+  uint32_t acc = 0;                                   // bits shifted out at the top are older than 14 positions
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc = (acc << bps) | ((cw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+  return acc;
+}
+// bits of stream word `w` that belong to the frame (the padding of the last word stays 0 after descrambling as well)
+__device__ __forceinline__ uint32_t descr_mask(int n_codes, int bps, int w) {
+  const int valid = n_codes * bps - 32 * w;
+  return valid >= 32 ? 0xffffffffu : (valid <= 0 ? 0u : ~(0xffffffffu >> valid));
+}
+
 // Pack stage of a frame: decided symbols `codes` (one byte each, LDS, zero-padded to a multiple of 32) -> packed bits
 // (bit i of the frame -> byte i/8, bit 7 - i%8) + this thread's share of the BER numerator.  A group of 32 symbols is
 // exactly `bps` 32-bit words.  BPS > 0 (square QAM, bps known at compile time): every shift is a constant, the group's
 // reference words are requested before anything else and the stores leave at the end -- with a run-time bps the
 // compiler emitted store -> load -> s_waitcnt vmcnt(0) once per word, up to eight dependent HBM round trips per thread
 // (12 % of a frame's workgroup time in the in-kernel timestamps).  BPS = 0: run-time bps (any constellation).
-template <int BPS>
-__device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes, int n_codes, int bps_rt, int frame_words,
-                                               uint32_t* __restrict__ out_f, const uint32_t* __restrict__ ref_f, int tid,
-                                               int nthr) {
+// descr & DESCR_ON: the words are descrambled before they are stored / compared (ref_f then holds the TX's INPUT bits).
+// DESCR is a template parameter because the wave-per-frame kernel packs with ~40 prefetched samples live: a run-time switch
+// there cost 20 more spilled registers in the default mode.
+template <int BPS, bool DESCR>
+__device__ __forceinline__ unsigned pack_frame_t(const uint8_t* __restrict__ codes, int n_codes, int bps_rt, int frame_words,
+                                                 uint32_t* __restrict__ out_f, const uint32_t* __restrict__ ref_f, int tid,
+                                                 int nthr, uint32_t descr) {
   unsigned err = 0;
   const int n_groups = (n_codes + 31) >> 5;
   for (int grp = tid; grp < n_groups; grp += nthr) {
@@ -506,14 +535,24 @@ __device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes
         nb += BPS;
         if (nb >= 32) {
           nb -= 32;
-          word[wi++] = __builtin_bswap32((uint32_t)(acc >> nb));
+          word[wi++] = (uint32_t)(acc >> nb);
+        }
+      }
+      if constexpr (DESCR) {
+        uint32_t prev = grp == 0 ? descr : descr_tail(codes, 32 * grp, BPS);
+#pragma unroll
+        for (int j = 0; j < BPS; ++j) {
+          const uint32_t raw = word[j];
+          word[j] = descr_word(raw, prev) & descr_mask(n_codes, BPS, w0 + j);
+          prev = raw;
         }
       }
 #pragma unroll
       for (int j = 0; j < BPS; ++j) {
         if (w0 + j < frame_words) {
-          if (out_f) out_f[w0 + j] = word[j];
-          if (ref_f) err += __popc(word[j] ^ refw[j]);
+          const uint32_t wd = __builtin_bswap32(word[j]);
+          if (out_f) out_f[w0 + j] = wd;
+          if (ref_f) err += __popc(wd ^ refw[j]);
         }
       }
     } else {
@@ -522,13 +561,21 @@ __device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes
       const uint32_t cw[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
       unsigned long long acc = 0;
       int nb = 0, w = grp * bps_rt;
+      uint32_t prev = 0;
+      if constexpr (DESCR) prev = grp == 0 ? descr : descr_tail(codes, 32 * grp, bps_rt);
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
         acc = (acc << bps_rt) | ((cw[i >> 2] >> (8 * (i & 3))) & 0xffu);
         nb += bps_rt;
         if (nb >= 32) {
           nb -= 32;
-          const uint32_t wd = __builtin_bswap32((uint32_t)(acc >> nb));
+          uint32_t raw = (uint32_t)(acc >> nb);
+          if constexpr (DESCR) {
+            const uint32_t d = descr_word(raw, prev) & descr_mask(n_codes, bps_rt, w);
+            prev = raw;
+            raw = d;
+          }
+          const uint32_t wd = __builtin_bswap32(raw);
           if (w < frame_words) {
             if (out_f) out_f[w] = wd;
             if (ref_f) err += __popc(wd ^ ref_f[w]);
@@ -539,6 +586,15 @@ __device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes
     }
   }
   return err;
+}
+
+// run-time form for the kernels whose pack stage is not register-critical (the switch is workgroup-uniform)
+template <int BPS>
+__device__ __forceinline__ unsigned pack_frame(const uint8_t* __restrict__ codes, int n_codes, int bps_rt, int frame_words,
+                                               uint32_t* __restrict__ out_f, const uint32_t* __restrict__ ref_f, int tid,
+                                               int nthr, uint32_t descr = 0) {
+  if (descr & DESCR_ON) return pack_frame_t<BPS, true>(codes, n_codes, bps_rt, frame_words, out_f, ref_f, tid, nthr, descr);
+  return pack_frame_t<BPS, false>(codes, n_codes, bps_rt, frame_words, out_f, ref_f, tid, nthr, 0u);
 }
 
 // What the fast / split paths need to know about an RX plan (ofdm_chain.hip owns the plan)
@@ -559,6 +615,7 @@ struct FastPlanView {
   void** ws_x;             // split path workspace: X(1..N_carrier, :) of every symbol [n_frames * n_symb][n_carrier]
   int64_t* ws_x_elems;
   int data_mod4;           // bit r: a data carrier with 0-based index = r (mod 4) exists (the wave symbol kernel skips the other residues)
+  uint32_t descr;          // per-frame DeScrambler of the pack stage: 0 or DESCR_ON | register bits (ofdm_rx_plan_set_descrambler)
 };
 
 template <typename T>

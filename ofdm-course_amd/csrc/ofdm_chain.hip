@@ -318,6 +318,58 @@ __global__ __launch_bounds__(fft_wg_threads(N)) void rx_chain_kernel(ChainParams
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Per-frame DeScrambler as a pass over the packed decisions (T5/DeScrambler.m:8-13, register reset per frame,
+// T5/Main_model_Task_5.m:257-274) for every path whose pack stage does not descramble itself -- all but the wave-per-frame
+// symbol kernel: the chain writes its raw decisions to a plan workspace, this pass writes the descrambled words to the
+// caller's bits_out and counts the errors against the TX's input bits.  One workgroup per frame, nothing atomic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void descr_pass_kernel(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
+                                                         const uint32_t* __restrict__ ref, uint32_t* __restrict__ errs,
+                                                         int frame_words, int64_t frame_bits, uint32_t descr) {
+  const int64_t f = blockIdx.x;
+  const uint32_t* r = raw + f * frame_words;
+  unsigned err = 0;
+  for (int w = threadIdx.x; w < frame_words; w += 256) {
+    const uint32_t cur = __builtin_bswap32(r[w]);                     // stream order: MSB first
+    const uint32_t prev = w ? __builtin_bswap32(r[w - 1]) : descr;
+    const int64_t valid = frame_bits - (int64_t)w * 32;
+    const uint32_t d = descr_word(cur, prev) & (valid >= 32 ? 0xffffffffu : ~(0xffffffffu >> (int)valid));
+    const uint32_t o = __builtin_bswap32(d);
+    if (out) out[f * frame_words + w] = o;
+    if (ref) err += __popc(o ^ ref[f * frame_words + w]);
+  }
+  if (ref && errs) {
+    for (int off = 32; off > 0; off >>= 1) err += __shfl_xor(err, off, 64);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = err;
+    __syncthreads();
+    if (threadIdx.x == 0) errs[f] = part[0] + part[1] + part[2] + part[3];
+  }
+}
+
+// workspace for the raw decisions of `n_frames` frames (plan-owned, grown on demand)
+int descr_raw_workspace(ofdm_rx_plan* pl, int64_t n_frames, void** raw) {
+  const size_t need = (size_t)pl->frame_words * 4 * (size_t)n_frames;
+  if (pl->ws_raw_bytes < need) {
+    OFDM_HIP(hipStreamSynchronize(ctx().stream));
+    if (pl->ws_raw) { (void)hipFree(pl->ws_raw); pl->ws_raw = nullptr; pl->ws_raw_bytes = 0; }
+    OFDM_HIP(hipMalloc(&pl->ws_raw, need));
+    pl->ws_raw_bytes = need;
+  }
+  *raw = pl->ws_raw;
+  return OFDM_OK;
+}
+
+int descr_pass_run(ofdm_rx_plan* pl, const void* raw, void* bits, const void* ref, void* errs, int64_t n_frames) {
+  if (n_frames == 0) return OFDM_OK;
+  hipLaunchKernelGGL(descr_pass_kernel, dim3((unsigned)n_frames), dim3(256), 0, ctx().stream, (const uint32_t*)raw,
+                     (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, pl->frame_words,
+                     (int64_t)pl->nd * pl->n_symb * pl->bps, pl->descr);
+  return check_launch("descr_pass_kernel");
+}
+
 }  // namespace ofdm
 
 using namespace ofdm;
@@ -478,11 +530,29 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
                   pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x,
-                  pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop};
+                  pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop, pl->ws_raw};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : pl->ev_t4) if (e) (void)hipEventDestroy(e);
   if (ctx().ready && ctx().device == pl->device && ctx().live_plans > 0) ctx().live_plans -= 1;
   delete pl;
+  return OFDM_OK;
+}
+
+// Per-frame DeScrambler of the fused receivers (T5/Main_model_Task_5.m:257-274, T4/Main_model_Task_4.m:354-364)
+int ofdm_rx_plan_set_descrambler(ofdm_rx_plan* pl, const uint8_t* reg15) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(pl, "rx_plan_set_descrambler: null plan");
+  uint32_t d = 0;
+  if (reg15) {
+    d = DESCR_ON;
+    for (int m = 1; m <= 14; ++m) {            // Register(15) never reaches a tap before it is shifted out (array_xor: 13, 14)
+      OFDM_ARG(reg15[m - 1] <= 1, "rx_plan_set_descrambler: register entries must be 0 or 1");
+      d |= (uint32_t)reg15[m - 1] << (m - 1);
+    }
+    OFDM_ARG(reg15[14] <= 1, "rx_plan_set_descrambler: register entries must be 0 or 1");
+  }
+  pl->descr = d;
   return OFDM_OK;
 }
 
@@ -519,8 +589,10 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double s
 
 int ofdm_rx_plan_set_timing(ofdm_rx_plan* pl, int enable) {
   OFDM_ARG(pl, "rx_plan_set_timing: null plan");
-  if (enable && !pl->ev[0])
+  if (enable && !pl->ev[0]) {
     for (int i = 0; i < 4; ++i) OFDM_HIP(hipEventCreate(&pl->ev[i]));
+    for (int i = 0; i < 6; ++i) OFDM_HIP(hipEventCreate(&pl->ev_t4[i]));
+  }
   pl->timing = enable ? 1 : 0;
   return OFDM_OK;
 }
@@ -539,6 +611,13 @@ int ofdm_rx_plan_last_kernel_ms(ofdm_rx_plan* pl, float* ms3) {
     ms3[0] = ms3[1] = 0.f;
     OFDM_HIP(hipEventElapsedTime(&ms3[2], pl->ev[0], pl->ev[3]));
   }
+  return OFDM_OK;
+}
+
+int ofdm_rx_plan_last_task4_ms(ofdm_rx_plan* pl, float* ms5) {
+  OFDM_ARG(pl && ms5 && pl->timing && pl->ev_t4[0] && pl->t4_timed, "rx_plan_last_task4_ms: no timed ofdm_rx_chain_task4 call");
+  OFDM_HIP(hipEventSynchronize(pl->ev_t4[5]));
+  for (int i = 0; i < 5; ++i) OFDM_HIP(hipEventElapsedTime(&ms5[i], pl->ev_t4[i], pl->ev_t4[i + 1]));
   return OFDM_OK;
 }
 
@@ -573,23 +652,44 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
   if (!fast && pl->pilots_in_band &&
       chain_split_supported(pl->nfft, pl->n_carrier, pl->taps, pl->bps, (int64_t)pl->nd * pl->n_symb, pl->f64 != 0))
     split = pl->nfft > 4096 || pl->d_wt != nullptr || generic_lds_bytes(pl) > GENERIC_LDS_LIMIT;
+  // DeScrambler of the plan: fused into the pack stage of the wave-per-frame symbol kernel; every other path hands its raw
+  // decisions to descr_pass_kernel (the stages themselves then neither compare nor count)
+  void* craw = nullptr;
+  bool descr_pass = false;
   if (fast || split) {
     FastPlanView pv;
     make_plan_view(pl, pv);
     pl->last_fast = 1;
-    if (fast) OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx));
-    else OFDM_TRY(chain_split_run(pv, tw, drx, n_frames, dbits, dref, derr, dh, didx, (const int32_t*)pl->d_pc0));
+    descr_pass = (pl->descr & DESCR_ON) && !(fast && chain_wave_supported(pv));
+    if (descr_pass) {
+      OFDM_TRY(descr_raw_workspace(pl, n_frames, &craw));
+      pv.descr = 0;
+    }
+    void* cb = descr_pass ? craw : dbits;
+    const void* cr = descr_pass ? nullptr : dref;
+    void* ce = descr_pass ? nullptr : derr;
+    if (fast) OFDM_TRY(chain_fast_run(pv, tw, drx, n_frames, cb, cr, ce, dh, didx));
+    else OFDM_TRY(chain_split_run(pv, tw, drx, n_frames, cb, cr, ce, dh, didx, (const int32_t*)pl->d_pc0));
+    if (descr_pass) OFDM_TRY(descr_pass_run(pl, craw, dbits, dref, derr, n_frames));
     return st.finish();
   }
+  descr_pass = (pl->descr & DESCR_ON) != 0;
+  if (descr_pass) OFDM_TRY(descr_raw_workspace(pl, n_frames, &craw));
   OFDM_ARG(!pl->d_wt, "rx_chain_task5: the MMSE mode of a plan needs pilots inside 1..N_carrier, at most 32 taps and a frame "
                       "whose decisions fit the workgroup's LDS (ofdm_MMSE_CE covers every other case)");
   pl->last_fast = 0;
   if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[0], ctx().stream));
-#define CALL(NN)                                                                                              \
-  if (pl->f64) OFDM_TRY((launch_chain<double, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));      \
-  else OFDM_TRY((launch_chain<float, NN>(pl, tw, drx, n_frames, dbits, dref, derr, dh, didx)));
-  OFDM_FFT_DISPATCH(pl->nfft, CALL)
+  {
+    void* cb = descr_pass ? craw : dbits;
+    const void* cr = descr_pass ? nullptr : dref;
+    void* ce = descr_pass ? nullptr : derr;
+#define CALL(NN)                                                                                        \
+  if (pl->f64) OFDM_TRY((launch_chain<double, NN>(pl, tw, drx, n_frames, cb, cr, ce, dh, didx)));       \
+  else OFDM_TRY((launch_chain<float, NN>(pl, tw, drx, n_frames, cb, cr, ce, dh, didx)));
+    OFDM_FFT_DISPATCH(pl->nfft, CALL)
 #undef CALL
+  }
+  if (descr_pass) OFDM_TRY(descr_pass_run(pl, craw, dbits, dref, derr, n_frames));
   if (pl->timing) OFDM_HIP(hipEventRecord(pl->ev[3], ctx().stream));
   return st.finish();
 }

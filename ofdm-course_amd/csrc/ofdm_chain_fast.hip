@@ -409,6 +409,7 @@ int fast_params_prepare(const FastPlanView& pv, const void* tw, int64_t n_frames
     OFDM_HIP(hipMalloc(pv.ws_h, sizeof(cx<T>) * (size_t)pv.n_carrier * *pv.ws_frames));
   }
   P.h_in = mmse ? (const cx<T>*)*pv.ws_h : nullptr;
+  P.descr = pv.descr;
   return OFDM_OK;
 }
 template int fast_params_prepare<float>(const FastPlanView&, const void*, int64_t, FastParams<float>&);

@@ -45,7 +45,9 @@ constexpr int WV_WPB = 4;              // wavefronts (= frames in flight) per wo
 constexpr unsigned WV_OFF_TW = 0, WV_OFF_TWB = 8 * 64 * WV_TW_ROWS, WV_OFF_DD = WV_OFF_TWB + 8 * 64 * 7;
 constexpr unsigned WV_OFF_LUT = WV_OFF_DD + 8 * 64 * 4;              // decision thresholds of demap_square_lut
 constexpr unsigned WV_OFF_WAVE = WV_OFF_LUT + 256;
-constexpr unsigned WV_TRASH_OFF = 8 * WV_TR_ELEMS, WV_CODES_OFF = WV_TRASH_OFF + 8 * 64;
+constexpr unsigned WV_TRASH_OFF = 8 * WV_TR_ELEMS, WV_DESCR_OFF = WV_TRASH_OFF + 8 * 64, WV_CODES_OFF = WV_DESCR_OFF + 16;
+// (WV_DESCR_OFF: one word per wavefront, the DeScrambler state between the pack batches of a frame -- in LDS so that it
+//  costs no register across the symbol loop)
 struct WaveLayout {
   unsigned wave_bytes, total;
   int cb;                                 // symbols per pack batch
@@ -86,7 +88,7 @@ __device__ __forceinline__ int slice_wave(const DemapTable<float>& tab, const fl
   else return slice_symbol<float, BA, true>(tab, z);
 }
 
-template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, int LUT = 2, int SKIP = 0>
+template <int BA, bool HEXT, int WPB = WV_WPB, int ABL = 0, bool WBUF = true, int LUT = 2, int SKIP = 0, bool DESCR = false>
 __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_kernel(FastParams<float> P, WaveLayout lay,
                                                                   const cx<float>* __restrict__ rx, int64_t n_frames,
                                                                   uint32_t* __restrict__ bits_out,
@@ -229,6 +231,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
     unsigned err = 0;
     int slot = 1;                                                      // symbols in the codes buffer
     int64_t code0 = 0;                                                 // first code index of the buffer within the frame
+    uint32_t* const dslot = (uint32_t*)(smem + wbase + WV_DESCR_OFF);  // DeScrambler state at the start of the pack batch
+    if constexpr (DESCR) { if (lane == 0) *dslot = P.descr; }
     auto symbol = [&](auto LC, int s) __attribute__((always_inline)) {
       constexpr int L = decltype(LC)::value;
       // where the registers of a finished round are refilled from: the next symbol of this wavefront's stream
@@ -319,9 +323,16 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
         if (lane < pad_to - n_codes) codes[n_codes + lane] = 0;
         wave_sync();
         const int woff = (int)(code0 >> 5) * P.bps;                   // code0 is a multiple of 32
-        err += pack_frame<2 * BA>(codes, n_codes, P.bps, P.frame_words - woff,
+        uint32_t dprev = 0;
+        if constexpr (DESCR) dprev = *dslot;
+        err += pack_frame_t<2 * BA, DESCR>(codes, n_codes, P.bps, P.frame_words - woff,
                                   bits_out ? bits_out + f * P.frame_words + woff : nullptr,
-                                  ref_bits ? ref_bits + f * P.frame_words + woff : nullptr, lane, 64);
+                                  ref_bits ? ref_bits + f * P.frame_words + woff : nullptr, lane, 64, dprev);
+        // DeScrambler on: the next batch continues the frame's stream -- hand it the last 14 bits of this one (a batch that
+        // is not the frame's last ends on a 32-code boundary)
+        if (DESCR && s + 1 < n_symb) {
+          if (lane == 0) *dslot = DESCR_ON | (descr_tail(codes, n_codes, P.bps) & 0x3fffu);
+        }
         wave_sync();
         code0 += n_codes;
         slot = 0;
@@ -335,8 +346,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 8 ? 4 : 3) void rx_symbols_wave_ke
       const int n_codes = nd, pad_to = (n_codes + 31) & ~31;
       if (lane < pad_to - n_codes) codes[n_codes + lane] = 0;
       wave_sync();
-      err += pack_frame<2 * BA>(codes, n_codes, P.bps, P.frame_words, bits_out ? bits_out + f * P.frame_words : nullptr,
-                                ref_bits ? ref_bits + f * P.frame_words : nullptr, lane, 64);
+      err += pack_frame_t<2 * BA, DESCR>(codes, n_codes, P.bps, P.frame_words, bits_out ? bits_out + f * P.frame_words : nullptr,
+                                         ref_bits ? ref_bits + f * P.frame_words : nullptr, lane, 64, P.descr);
       wave_sync();
     }
     if (ref_bits && errors_out) {
@@ -377,6 +388,7 @@ static bool wave_layout(int nd, int n_symb, int wpb, WaveLayout& lay) {
 
 bool chain_wave_supported(const FastPlanView& pv) {
   if (getenv("OFDM_FAST_NO_WAVE")) return false;
+  if ((pv.descr & DESCR_ON) && pv.d_wt != nullptr) return false;      // DeScrambler + MMSE mode: the four-wavefront symbol stage
   if (pv.f64 || pv.nfft != WV_N || pv.n_carrier > WV_N / 4 || pv.taps > FAST_MAXT) return false;
   WaveLayout lay;
   return wave_layout(pv.nd, pv.n_symb, 4, lay) && wave_layout(pv.nd, pv.n_symb, 8, lay);
@@ -413,7 +425,21 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
   else if (skip0) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 2, 1>));    \
   else if (skip02) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4, 0, true, 2, 5>));   \
   else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, HX, 4>))
-  if (mmse) {
+  // per-frame DeScrambler in the pack stage (ofdm_rx_plan_set_descrambler): its own instantiations, OMP mode only
+#define WAVE_CASE_D(BAV)                                                                            \
+  if (exact) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, false, 4, 0, true, 0, 0, true>));          \
+  else if (skip0) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, false, 4, 0, true, 2, 1, true>));     \
+  else if (skip02) OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, false, 4, 0, true, 2, 5, true>));    \
+  else OFDM_TRY(launch(rx_symbols_wave_kernel<BAV, false, 4, 0, true, 2, 0, true>))
+  if (P.descr & DESCR_ON) {
+    OFDM_ARG(!mmse, "rx_chain_task5(wave): the DeScrambler variant exists in OMP mode only");
+    switch (ba) {
+      case 2: WAVE_CASE_D(2); break;
+      case 3: WAVE_CASE_D(3); break;
+      case 4: WAVE_CASE_D(4); break;
+      default: WAVE_CASE_D(0); break;
+    }
+  } else if (mmse) {
     switch (ba) {
       case 2: WAVE_CASE(2, true); break;
       case 3: WAVE_CASE(3, true); break;
@@ -434,6 +460,7 @@ int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, c
     }
   }
 #undef WAVE_CASE
+#undef WAVE_CASE_D
   return check_launch("rx_symbols_wave_kernel");
 }
 

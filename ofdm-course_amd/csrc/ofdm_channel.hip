@@ -1,5 +1,6 @@
 // Channel side: get_MP_channel_resp + the inline conv of the drivers, Noise (counter-based AWGN),
 // add_STO, add_CFO.
+#include <algorithm>
 #include <type_traits>
 
 #include "ofdm_common.hpp"
@@ -153,6 +154,48 @@ __global__ void cfo_kernel(const cx<T>* __restrict__ y, cx<T>* __restrict__ out,
     const cx<T> v = y[i];
     out[i] = mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
   }
+}
+
+// add_STO then add_CFO of a batch of frames, every frame with its own draw (T4/Main_model_Task_4.m:101-110 per Monte-Carlo
+// run): out[f][i] = (i + sto_f < len ? y[f][i + sto_f] : 0) * exp(2j*pi*cfo_f*i/Nfft) -- add_STO.m:5-9 (either sign) followed
+// by add_CFO.m:6-7 on the shifted stream, the rotation with the arithmetic of cfo_kernel.  sto == nullptr / cfo == nullptr
+// leave the stage out.  grid.y = frame.
+template <typename T>
+__global__ void sto_cfo_frames_kernel(const cx<T>* __restrict__ yall, cx<T>* __restrict__ outall, int64_t len,
+                                      const int64_t* __restrict__ sto, const double* __restrict__ cfo, double inv_nfft) {
+  const cx<T>* y = yall + (int64_t)blockIdx.y * len;
+  cx<T>* out = outall + (int64_t)blockIdx.y * len;
+  const int64_t n_sto = sto ? sto[blockIdx.y] : 0;
+  const double f = cfo ? cfo[blockIdx.y] : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = i + n_sto;
+    cx<T> v = (src >= 0 && src < len) ? y[src] : mk<T>(0, 0);
+    if (cfo) {
+      const double t = f * (double)i * inv_nfft;
+      const double fr = t - floor(t);
+      double sn, cs;
+      sincospi(2.0 * fr, &sn, &cs);
+      v = mk<T>((T)((double)v.x * cs - (double)v.y * sn), (T)((double)v.x * sn + (double)v.y * cs));
+    }
+    out[i] = v;
+  }
+}
+
+int sto_cfo_frames_device(const void* y, void* out, int64_t len, int64_t n_frames, const int64_t* d_sto, const double* d_cfo,
+                          int nfft, bool f64) {
+  if (len == 0 || n_frames == 0) return OFDM_OK;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((len + 255) / 256, 64));
+  for (int64_t f0 = 0; f0 < n_frames; f0 += 65535) {
+    const int64_t nf = std::min<int64_t>(65535, n_frames - f0);
+    const dim3 grid(gx, (unsigned)nf);
+    if (f64)
+      hipLaunchKernelGGL(sto_cfo_frames_kernel<double>, grid, dim3(256), 0, ctx().stream, (const c64*)y + f0 * len,
+                         (c64*)out + f0 * len, len, d_sto ? d_sto + f0 : nullptr, d_cfo ? d_cfo + f0 : nullptr, 1.0 / (double)nfft);
+    else
+      hipLaunchKernelGGL(sto_cfo_frames_kernel<float>, grid, dim3(256), 0, ctx().stream, (const c32*)y + f0 * len,
+                         (c32*)out + f0 * len, len, d_sto ? d_sto + f0 : nullptr, d_cfo ? d_cfo + f0 : nullptr, 1.0 / (double)nfft);
+  }
+  return check_launch("sto_cfo_frames_kernel");
 }
 
 // device-pointer helpers reused by the sync code
@@ -336,6 +379,20 @@ int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, in
   OFDM_TRY(st.in(y, csize(flags) * (size_t)len, &dy));
   OFDM_TRY(st.out(out, csize(flags) * (size_t)len, &dout));
   OFDM_TRY(cfo_device(dy, dout, len, cfo, nfft, is_f64(flags)));
+  return st.finish();
+}
+
+int ofdm_add_STO_CFO_frames(const void* y, int64_t frame_len, int64_t n_frames, const int64_t* n_sto, const double* cfo, int nfft,
+                            void* out, int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(frame_len >= 0 && n_frames >= 0 && nfft > 0, "add_STO_CFO_frames: bad sizes");
+  Stage st(flags);
+  const void *dy, *dsto = nullptr, *dcfo = nullptr; void* dout;
+  OFDM_TRY(st.in(y, csize(flags) * (size_t)frame_len * n_frames, &dy));
+  if (n_sto) OFDM_TRY(st.in(n_sto, sizeof(int64_t) * (size_t)n_frames, &dsto));
+  if (cfo) OFDM_TRY(st.in(cfo, sizeof(double) * (size_t)n_frames, &dcfo));
+  OFDM_TRY(st.out(out, csize(flags) * (size_t)frame_len * n_frames, &dout));
+  OFDM_TRY(sto_cfo_frames_device(dy, dout, frame_len, n_frames, (const int64_t*)dsto, (const double*)dcfo, nfft, is_f64(flags)));
   return st.finish();
 }
 

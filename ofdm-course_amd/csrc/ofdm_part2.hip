@@ -423,6 +423,7 @@ extern "C" int ofdm_task5_part2_tile(ofdm_rx_plan* pl, const void* tx_noised, co
                                      int n_ch_taps, int64_t n_frames, double snr_db, const uint8_t* ref_bits, double* nmse_out,
                                      uint32_t* errors_out, int flags) {
   OFDM_TRY(ensure_init());
+  OFDM_ARG(!pl || !(pl->descr & DESCR_ON), "task5_part2_tile: the study runs unscrambled (Task5_part2.m:104-114,:285-299 are commented out); clear the plan's DeScrambler");
   OFDM_ARG(pl && tx_noised && tap_delay && tap_amp && ref_bits && nmse_out && errors_out, "task5_part2_tile: null argument");
   OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "task5_part2_tile: precision flag differs from the plan's");

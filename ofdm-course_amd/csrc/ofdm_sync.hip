@@ -805,6 +805,12 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   dres = arena + o_res; dresv = arena + o_resv; dy = arena + o_y; dX = arena + o_X; dest = arena + o_est;
   dhp = arena + o_hp; dH = arena + o_H;
   void* dXp = arena + o_Xp;
+  // stage brackets (ofdm_rx_plan_set_timing): [0] start, [1] AutoCorrFunction stage, [2] remove_IFO stage, [3] demodulator,
+  // [4] fine_sync + estimate_channel, [5] equalise / demap / (DeScrambler)
+  const bool timed = pl->timing && pl->ev_t4[0];
+  pl->t4_timed = timed ? 1 : 0;
+  auto mark = [&](int i) { if (timed) (void)hipEventRecord(pl->ev_t4[i], s); };
+  mark(0);
   // per-frame scalars and the unresolved-frame counter start at zero: one launch instead of five memsets (4.7 us each)
   hipLaunchKernelGGL(t4_init_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, dstat, dtg, dfo, difo, (int32_t*)(arena + o_flist), F);
   if (sync) {
@@ -838,6 +844,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
                        dtg, dfo, dstat, F);
     OFDM_TRY(check_launch("AutoCorrFunction stage"));
   }
+  mark(1);
   const unsigned gl = (unsigned)std::min<int64_t>((len + 255) / 256, 64);
   const int td_eff = sync ? time_desync : 0, fd_eff = sync ? freq_desync : 0;
   const bool direct = (N == 512 || N == 1024 || N == 2048 || N == 4096) && !getenv("OFDM_T4_STAGED");
@@ -854,6 +861,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
       hipLaunchKernelGGL(t4_ifo_finalize_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dfirst, difo, dstat, F);
       OFDM_TRY(check_launch("remove_IFO stage"));
     }
+    mark(2);
     const void* twd = nullptr;
     OFDM_TRY(get_twiddles(N, f64, &twd));
     switch (N / 512) {
@@ -875,8 +883,10 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
       hipLaunchKernelGGL(t4_ifo_kernel<T>, dim3(gl, (unsigned)F), dim3(256), 0, s, (cx<T>*)dy, len, N, (const int64_t*)dfirst, difo, dstat);
       OFDM_TRY(check_launch("remove_IFO stage"));
     }
+    mark(2);
     OFDM_TRY(demod_device(dy, dX, N, (int64_t)S * F, Tg, f64));                       // T4:308-310
   }
+  mark(3);
   // pilot matrix [np x S] = the plan's pilot column on every symbol (T4:28-31) and the spline operator of
   // estimate_channel.m:8 for rows 1..N_carrier: built once per plan, kept on the device
   if (!pl->d_t4_tx) {
@@ -919,6 +929,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     hipLaunchKernelGGL(t4_fill_ones_kernel<T>, dim3(256), dim3(256), 0, s, (cx<T>*)dH, (int64_t)nc * F);
   }
   OFDM_TRY(check_launch("estimate_channel stage"));
+  mark(4);
   FastPlanView pv2;
   make_plan_view(pl, pv2);
   pv2.ev = nullptr;
@@ -927,8 +938,15 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   OFDM_TRY(get_twiddles(N, f64, &tw));
   OFDM_TRY(fast_params_prepare<T>(pv2, tw, F, P));
   P.h_in = (const cx<T>*)dH;
-  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, direct ? nc : N, true, F, dbits, dref, derr, dh_out, nullptr, lazy_rot,
+  // the per-frame DeScrambler of T4:354-364 (ofdm_rx_plan_set_descrambler) as a pass over the packed decisions
+  const bool descr_pass = (pl->descr & DESCR_ON) != 0;
+  void* craw = nullptr;
+  if (descr_pass) OFDM_TRY(descr_raw_workspace(pl, F, &craw));
+  OFDM_TRY(eq_demap_run<T>(pv2, P, (const cx<T>*)dX, direct ? nc : N, true, F, descr_pass ? craw : dbits,
+                           descr_pass ? nullptr : dref, descr_pass ? nullptr : derr, dh_out, nullptr, lazy_rot,
                            time_desync, freq_desync));                                                                   // T4:334-347
+  if (descr_pass) OFDM_TRY(descr_pass_run(pl, craw, dbits, dref, derr, F));
+  mark(5);
   return OFDM_OK;
 }
 

@@ -23,6 +23,8 @@ struct ofdm_rx_plan {
   int64_t ws_frames = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int timing = 0;          // ofdm_rx_plan_set_timing
+  hipEvent_t ev_t4[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage brackets of ofdm_rx_chain_task4
+  int t4_timed = 0;        // the last ofdm_rx_chain_task4 call recorded them
   int last_fast = 0;
   int last_fused = 0;      // fast path ran rx_pilot_omp_kernel instead of rx_pilot_kernel + omp_batch_kernel
   ofdm::ConstellationInfo cinfo;
@@ -34,6 +36,9 @@ struct ofdm_rx_plan {
   void* d_t4_w = nullptr;
   void* ws_t4 = nullptr;   // ofdm_rx_chain_task4: arena for its per-batch intermediates
   size_t ws_t4_bytes = 0;
+  void* ws_raw = nullptr;  // raw packed decisions of a batch when the DeScrambler runs as a pass of its own (descr_pass_kernel)
+  size_t ws_raw_bytes = 0;
+  uint32_t descr = 0;      // per-frame DeScrambler of the pack stages (ofdm_rx_plan_set_descrambler): 0 or DESCR_ON | register bits
   void* d_p2_sop = nullptr; // ofdm_task5_part2_tile: spline operator of interpolate.m [n_carrier x np], double
 };
 
@@ -45,6 +50,12 @@ struct ofdm_rx_plan {
       return OFDM_ERR_STATE;                                                                                     \
     }                                                                                                            \
   } while (0)
+
+// ofdm_chain.hip: DeScrambler as a pass over the packed decisions (every path but the wave-per-frame symbol kernel)
+namespace ofdm {
+int descr_raw_workspace(ofdm_rx_plan* pl, int64_t n_frames, void** raw);
+int descr_pass_run(ofdm_rx_plan* pl, const void* raw, void* bits, const void* ref, void* errs, int64_t n_frames);
+}
 
 // view of a plan for the fast / split stages
 inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {
@@ -62,4 +73,5 @@ inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {
   pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
   pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
   pv.data_mod4 = pl->data_mod4;
+  pv.descr = pl->descr;
 }

@@ -102,7 +102,7 @@ def unpack_bits(packed: np.ndarray, n_bits: int) -> np.ndarray:
     return np.unpackbits(p, axis=1, bitorder="big")[:, :n_bits]
 
 
-def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise=True, frame0=0):
+def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise=True, frame0=0, noise_first=False):
     """Synthetic RX frames through the product's own TX + channel kernels.
 
     Returns dict(rx=[frame_samples, n_frames] complex (torch.cuda if device is not None else numpy),
@@ -110,6 +110,9 @@ def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise
     Global frame g = frame0 + f draws its payload from PCG64(seed, g) and its noise from Philox key `seed`, stream g
     (each frame is one Noise() call, i.e. the SNR is relative to that frame's measured power, as in
     T5/Task5_part2.m:134) -- so results do not depend on how frames are sharded over GPUs.
+    noise_first=True is the order of the reference's drivers, Noise -> conv(h) (T5/Main_model_Task_5.m:106-127,
+    T5/Task5_part2.m:134,:152): the SNR is set on the TX signal and the channel colours the noise; the default (False)
+    is conv(h) -> Noise, the SNR set at the receiver's input.
     """
     cdt = np.complex128 if precision == "fp64" else np.complex64
     nb = frame_bits(cfg, api)
@@ -135,20 +138,23 @@ def make_frames(cfg, api, n_frames, seed=1, precision="fp32", device=None, noise
                                   pv.astype(cdt))
         tx = api.OFDM_modulator(X, cfg.T_guard)
         flat = np.asarray(tx).reshape((cfg.frame_samples, n_frames), order="F")
-    # per-frame stream: the conv transient of a frame falls inside its first CP
-    rx = api.apply_channel_frames(flat, h)
-    if noise:
+    def add_noise(rx):
         if n_frames <= CH:
-            rx = api.Noise_frames(cfg.SNR_dB, rx, seed=seed, stream0=frame0)
-        else:
-            parts = []
-            for f0 in range(0, n_frames, CH):
-                parts.append(api.Noise_frames(cfg.SNR_dB, rx[:, f0:f0 + CH], seed=seed, stream0=frame0 + f0))
-            if device is not None:
-                import torch
-                rx = torch.cat([p.t() for p in parts], dim=0).t()
-            else:
-                rx = np.concatenate(parts, axis=1)
+            return api.Noise_frames(cfg.SNR_dB, rx, seed=seed, stream0=frame0)
+        parts = []
+        for f0 in range(0, n_frames, CH):
+            parts.append(api.Noise_frames(cfg.SNR_dB, rx[:, f0:f0 + CH], seed=seed, stream0=frame0 + f0))
+        if device is not None:
+            import torch
+            return torch.cat([p.t() for p in parts], dim=0).t()
+        return np.concatenate(parts, axis=1)
+    # per-frame stream: the conv transient of a frame falls inside its first CP
+    if noise and noise_first:
+        rx = api.apply_channel_frames(add_noise(flat), h)
+    else:
+        rx = api.apply_channel_frames(flat, h)
+        if noise:
+            rx = add_noise(rx)
     return dict(rx=rx, bits=bits, packed=pack_bits(bits), pilots=pv_col)
 
 
@@ -158,10 +164,10 @@ def make_plan(cfg, api, precision="fp32", device=None):
                       device=device)
 
 
-def make_frames_device(cfg, api, plan, n_frames, seed=1, device=None, noise=True, frame0=0, want_bits=False):
+def make_frames_device(cfg, api, plan, n_frames, seed=1, device=None, noise=True, frame0=0, want_bits=False, **kw):
     """Same role as make_frames, generated entirely on the device by the plan (ofdm_tx_frames): no host payload, no host
     packing -- what the sharded sweeps use.  The payload is the library's Philox draw (not make_frames' PCG64 bits), so the
     two generators give different -- equally valid -- frames."""
     h, _ = api.get_MP_channel_resp(cfg.taps, cfg.Nfft)
     return plan.tx_frames(n_frames, h=h, SNR=cfg.SNR_dB if noise else None, seed=seed, frame0=frame0, device=device,
-                          want_bits=want_bits)
+                          want_bits=want_bits, **kw)

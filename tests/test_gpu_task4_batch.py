@@ -224,3 +224,45 @@ def test_batch_against_oracle_replay_nfft2048_many_draws(ofdm, oracle):
         assert np.count_nonzero(got_bits[f] != want) <= 2, f
         decoded += 1
     assert failed >= 1 and decoded >= 3, (failed, decoded)
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_batch_on_generated_frames_with_descrambler(ofdm, oracle, precision):
+    """The Task-4 link end to end on the device: ofdm_tx_frames_ex (Scrambler per frame, Noise -> random add_STO / add_CFO ->
+    conv, T4/Main_model_Task_4.m:46-57,:94-110,:257-267) -> ofdm_rx_chain_task4 with the plan's DeScrambler
+    (T4:354-364).  The descrambled bits are DeScrambler.m of the raw decisions, the raw decisions equal the per-function
+    chain's, and the error counter is the descrambled one against the payload."""
+    from ofdm_course_amd import frames as fr
+    from ofdm_course_amd.drivers import common as dc
+    REG = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)
+    cfg_kw = dict(Nfft=1024, N_carrier=400, N_symb=10, const="16QAM")
+    Nfft, N_carrier, N_symb, const = 1024, 400, 10, "16QAM"
+    Tg = Nfft // 8
+    allc, pil, dat = dc.layout_percent(Nfft, N_carrier, 15, tail=2)
+    dd, bps = ofdm.constellation_func(const)
+    col = dc.alternating_pilots(4 / 3 * float(np.max(np.abs(dd))), len(pil), 1)[:, 0]
+    K = int(np.ceil(N_carrier / 6))
+    plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, col, K, 3, const, precision=precision)
+    h, _ = oracle.get_MP_channel_resp(np.array([[0, 1.0], [4, 0.6], [10, 0.3]]), Nfft)
+    nfr = 8
+    gen = plan.tx_frames(nfr, h=h, SNR=30.0, seed=21, frame0=5, want_bits=True, Register=REG, Time_Delay="random",
+                         Freq_Shift="random", noise_first=True, want_draws=True)
+    rx = np.asarray(gen["rx"])
+    raw = ofdm.rx_chain_task4(plan, rx, 1, 1, 1, ref_bits_packed=np.asarray(gen["sc_packed"]))
+    plan.set_descrambler(REG)
+    dsc = ofdm.rx_chain_task4(plan, rx, 1, 1, 1, ref_bits_packed=np.asarray(gen["packed"]))
+    plan.set_descrambler(None)
+    nb = plan.frame_bits
+    rb, db = fr.unpack_bits(np.asarray(raw["bits"]), nb), fr.unpack_bits(np.asarray(dsc["bits"]), nb)
+    d = dict(pil=pil, dat=dat, allc=allc, pv=np.repeat(col[:, None], N_symb, axis=1), Tg=Tg)
+    decoded = 0
+    for f in range(nfr):
+        assert np.array_equal(db[f], oracle.DeScrambler(REG, rb[f])[0])                       # the .m loop on the raw decisions
+        assert int(dsc["errors"][f]) == np.count_nonzero(db[f] != np.asarray(gen["bits"])[f])
+        assert int(raw["errors"][f]) == np.count_nonzero(rb[f] != fr.unpack_bits(np.asarray(gen["sc_packed"]), nb)[f])
+        ref = _per_function(ofdm, rx[:, f].copy(), d, cfg_kw, (1, 1, 1))
+        assert int(raw["status"][f]) == ref["status"] and int(dsc["status"][f]) == ref["status"]
+        if ref["status"] >= 0:
+            assert np.count_nonzero(rb[f] != ref["bits"]) <= (0 if precision == "fp64" else 4)
+            decoded += int(raw["errors"][f]) < 0.2 * nb
+    assert decoded >= 1                                                # the reference's own pass criterion (BER < 0.2, T4:367)

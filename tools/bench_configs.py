@@ -21,8 +21,20 @@ from ofdm_course_amd import frames as fr
 from ofdm_course_amd.drivers import common as dc
 
 dev = torch.device("cuda:0")
-ofdm.init(0)
 HBM = 8000.0
+
+
+def read_once_bytes(nfft, tg, nd, npil, n_symb, bps, C=8):
+    """Algorithmic bytes per OFDM symbol of a fused receiver, the M formula of SURVEY.md 8(d) for any geometry: the RX samples
+    read ONCE + packed decided bits written + reference bits read + the pilot column amortised over the frame.  Intermediates
+    (X, H, the autocorrelation curve, equalised IQ) are not counted -- whatever a receiver moves beyond this is overhead."""
+    return (nfft + tg) * C + 2 * nd * bps / 8.0 + npil * C / n_symb
+
+
+def roofline(b_sym, nsym, ms):
+    a = b_sym * nsym / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": HBM, "unit": "GB/s", "frac": a / HBM, "bytes_per_symbol": b_sym,
+            "basis": "read-once algorithmic bytes: samples once + bits out + reference bits in + pilots / N_symb"}
 
 
 def timed(fn, reps=5, warm=2, settle_s=0.3):
@@ -112,25 +124,7 @@ def c3():
            "BER": float(ofdm.BER_func(torch.from_numpy(bits).to(dev), out)),
            "note": "per_call = one 50-symbol frame per call sequence (11 launches + 3 host scalars), launch-latency bound; "
                    "batched = ofdm_rx_chain_task4 over 4096 frames with their own STO / CFO draws (1024 frames per call: 0.53 of the HBM peak, 4096: 0.60, 8192: 0.57)"}
-    # batched form: the same receiver over many frames in one call (ofdm_rx_chain_task4), each frame its own STO / CFO
-    F = 4096
-    rng = np.random.default_rng(3)
-    plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, pv[:, 0], int(np.ceil(N_carrier / 6)), 3, const,
-                       precision="fp32", device=0)
-    gen = plan.tx_frames(F, h=None, SNR=None, seed=9, device=dev)                       # clean TX frames, then per-frame impairments
-    rxb = torch.empty_like(gen["rx"].t().contiguous())
-    for f in range(F):
-        yf = gen["rx"][:, f].contiguous()
-        yf, _ = ofdm.Noise(30.0, yf, seed=9, stream=f)
-        yf = ofdm.add_CFO(ofdm.add_STO(yf, int(rng.integers(0, Nfft + Tg + 1))), float(rng.integers(0, 31)) + rng.random() - 0.5, Nfft)
-        rxb[f] = ofdm.apply_channel(yf, h)
-    rxb = rxb.t()
-    msb, outb = timed(lambda: ofdm.rx_chain_task4(plan, rxb, 1, 1, 1, ref_bits_packed=gen["packed"]), reps=5, warm=2)
-    okf = (outb["status"] >= 0)
-    res["batched"] = {"frames": F, "ms": msb, "sym_per_s": F * N_symb / msb * 1e3,
-                      "hbm_frac": (Nfft + Tg) * 8 * 3 * F * N_symb / (msb * 1e-3) / 1e9 / HBM,
-                      "frames_with_ifo_line": int(okf.sum().item()),
-                      "median_frame_BER": float(torch.median(outb["errors"].float() / plan.frame_bits).item())}
+    res["batched"] = c3_batched()
     # the O(L) autocorrelation alone on a long stream (HBM-bound kernel)
     long_rx = rx.repeat(200)
     ms2, _ = timed(lambda: ofdm.AutoCorrFunction(long_rx, Tg, Nfft), reps=5)
@@ -138,6 +132,39 @@ def c3():
     res["AutoCorrFunction_long_stream"] = {"symbols": nsym, "ms": ms2, "sym_per_s": nsym / ms2 * 1e3,
                                            "hbm_frac": 3 * 8 * long_rx.numel() / (ms2 * 1e-3) / 1e9 / HBM}
     return res
+
+
+def c3_batched(F=4096, reps=5):
+    """BASELINE config 3 as a batch: the Task-4 receiver (T4/Main_model_Task_4.m:278-347) over F frames of 50 symbols, every
+    frame with its own STO / CFO draw; the frames come from ONE device call (ofdm_tx_frames_ex: Noise -> add_STO -> add_CFO ->
+    conv, the reference's order, T4:94-110,:257-267) -- no host loop."""
+    Nfft, Tg, N_carrier, N_symb, const = 2048, 256, 800, 50, "64QAM"
+    allc, pil, dat = dc.layout_percent(Nfft, N_carrier, 15, tail=2)
+    d, bps = ofdm.constellation_func(const)
+    pv = dc.alternating_pilots(4 / 3 * float(np.max(np.abs(d))), len(pil), N_symb)
+    h, _ = ofdm.get_MP_channel_resp(np.array([[0, 1.0], [4, 0.6], [10, 0.3]]), Nfft)      # T4/Main_model_Task_4.m:257-261
+    plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, pv[:, 0], int(np.ceil(N_carrier / 6)), 3, const,
+                       precision="fp32", device=0)
+    gen = plan.tx_frames(F, h=h, SNR=30.0, seed=9, device=dev, Time_Delay="random", Freq_Shift="random", noise_first=True)
+    rxb = gen["rx"]
+    msb, outb = timed(lambda: ofdm.rx_chain_task4(plan, rxb, 1, 1, 1, ref_bits_packed=gen["packed"]), reps=reps, warm=2)
+    plan.set_timing(True)
+    k = []
+    for _ in range(3):
+        ofdm.rx_chain_task4(plan, rxb, 1, 1, 1, ref_bits_packed=gen["packed"])
+        k.append(plan.last_stage_ms())
+    plan.set_timing(False)
+    okf = (outb["status"] >= 0)
+    nsym = F * N_symb
+    r = {"workload": "C3: Nfft=2048 Tg=256 N_carrier=800 64QAM, frames of 50 symbols, 3-tap multipath + per-frame STO/CFO at 30 dB; "
+                     "AutoCorrFunction + remove_IFO + fine_sync + estimate_channel (LS + spline) + equalise + demap + BER",
+         "frames": F, "ms": msb, "sym_per_s": nsym / msb * 1e3,
+         "kernels_ms": {n: float(np.mean([x[n] for x in k])) for n in k[0]},
+         "roofline": roofline(read_once_bytes(Nfft, Tg, len(dat), len(pil), N_symb, bps), nsym, msb),
+         "frames_with_ifo_line": int(okf.sum().item()),
+         "median_frame_BER": float(torch.median(outb["errors"].float() / plan.frame_bits).item())}
+    plan.close()
+    return r
 
 
 def c4():
@@ -167,15 +194,23 @@ def c4():
                         "BER": float(sum(errs)) / bits.numel()}}
     del data, rx, bits
     torch.cuda.empty_cache()
-    # (b) batched: plan in MMSE mode = cached operator W applied as one GEMM on the matrix cores
-    F = 8192
-    data = fr.make_frames(cfg, ofdm, F, seed=4, precision="fp32", device=dev)
+    res["batched"] = c4_batched()
+    return res
+
+
+def c4_batched(F=8192, reps=20):
+    """BASELINE config 4 as a batch: plan in MMSE mode (MMSE_CE + interpolate for every frame, T5/Task5_part2.m:176-177)."""
+    cfg = fr.FrameConfig("C4", 4096, 1024, 4, "64QAM")
+    h, _ = ofdm.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+    hh = np.zeros(cfg.N_carrier, dtype=np.complex64)
+    hh[: len(h)] = h
     plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
+    data = fr.make_frames_device(cfg, ofdm, plan, F, seed=4, device=dev, noise_first=True)
     t0 = time.perf_counter()
     plan.set_mmse(hh, cfg.SNR_dB)
     t_plan = time.perf_counter() - t0
-    ref = torch.from_numpy(data["packed"]).to(dev)
-    ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=20, warm=5)
+    ref = data["packed"]
+    ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=reps, warm=5)
     plan.set_timing(True)
     k = []
     for _ in range(5):
@@ -184,51 +219,99 @@ def c4():
     k = np.mean(np.array(k), axis=0)
     nsym = F * cfg.N_symb
     _, bps = ofdm.constellation_func(cfg.Constellation)
-    b_sym = (cfg.Nfft + cfg.T_guard) * 8 + 2 * len(cfg.dataCarriers) * bps / 8 + len(cfg.pilotCarriers) * 8 / cfg.N_symb
     flops = 8.0 * cfg.N_carrier * len(cfg.pilotCarriers) * F
-    res["batched"] = {"frames": F, "ms": ms, "sym_per_s": nsym / ms * 1e3, "hbm_frac": b_sym * nsym / (ms * 1e-3) / 1e9 / HBM,
-                      "kernels_ms": {"rx_pilot_kernel": float(k[0]), "mmse_apply_mfma_kernel": float(k[1]),
-                                     "rx_symbols_kernel": float(k[2])},
-                      "mmse_gemm_tflops": flops / (float(k[1]) * 1e-3) / 1e12, "operator_build_s": t_plan,
-                      "BER": float(out["errors"].sum().item()) / (F * data["bits"].shape[1])}
-    return res
+    r = {"workload": "C4: Nfft=4096 Tg=512 N_carrier=1024 comb=4 64QAM, frames of 14, MMSE_CE + spline interpolation, 6-tap channel 20 dB",
+         "frames": F, "ms": ms, "sym_per_s": nsym / ms * 1e3,
+         "kernels_ms": {"rx_pilot_kernel": float(k[0]), "mmse_apply": float(k[1]), "rx_symbols": float(k[2])},
+         "roofline": roofline(read_once_bytes(cfg.Nfft, cfg.T_guard, len(cfg.dataCarriers), len(cfg.pilotCarriers), cfg.N_symb, bps),
+                              nsym, ms),
+         "mmse_gemm_tflops_dense_equivalent": flops / (float(k[1]) * 1e-3) / 1e12, "operator_build_s": t_plan,
+         "ber": float(out["errors"].sum().item()) / (F * plan.frame_bits)}
+    plan.close()
+    return r
+
+
+def c5_batched(F=3072, reps=5, generic=False):
+    """BASELINE config 5: Nfft 8192, 256QAM, 32-tap sparse channel, OMP with 32 taps, the fused chain's split form.
+    F = a multiple of 3 x 256 CUs x 4 frames: the 32-tap pursuit keeps three four-frame workgroups per CU resident."""
+    cfg = fr.config_C5()
+    plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
+    data = fr.make_frames_device(cfg, ofdm, plan, F, seed=5, device=dev, noise_first=True)
+    ref = data["packed"]
+    nsym = F * cfg.N_symb
+    _, bps = ofdm.constellation_func(cfg.Constellation)
+    b_sym = read_once_bytes(cfg.Nfft, cfg.T_guard, len(cfg.dataCarriers), len(cfg.pilotCarriers), cfg.N_symb, bps)
+    ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=reps, warm=2)
+    plan.set_timing(True)
+    k = []
+    for _ in range(5):
+        ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref)
+        k.append(plan.last_kernel_ms())
+    plan.set_timing(False)
+    k = np.mean(np.array(k), axis=0)
+    r = {"workload": "C5: Nfft=8192 Tg=1024 N_carrier=2048 comb=4 256QAM, frames of 14, OMP(32 taps) on a sparse 32-tap channel 20 dB",
+         "frames": F, "ms": ms, "sym_per_s": nsym / ms * 1e3,
+         "kernels_ms": {"symbol1+pilot_ls": float(k[0]), "omp_batch_kernel": float(k[1]), "symbols": float(k[2])},
+         "roofline": roofline(b_sym, nsym, ms),
+         "ber": float(out["errors"].sum().item()) / (F * plan.frame_bits)}
+    if generic:
+        os.environ["OFDM_CHAIN_GENERIC"] = "1"
+        try:
+            msg, outg = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=2, warm=1)
+        finally:
+            os.environ.pop("OFDM_CHAIN_GENERIC", None)
+        r["generic_single_kernel"] = {"ms": msg, "sym_per_s": nsym / msg * 1e3,
+                                      "ber": float(outg["errors"].sum().item()) / (F * plan.frame_bits)}
+    plan.close()
+    return r
 
 
 def c5():
-    cfg = fr.config_C5()
-    F = 3072       # a multiple of 3 x 256 CUs x 4 frames: the 32-tap pursuit keeps three four-frame workgroups per CU resident
-    data = fr.make_frames(cfg, ofdm, F, seed=5, precision="fp32", device=dev)
-    plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
-    ref = torch.from_numpy(data["packed"]).to(dev)
-    nsym = F * cfg.N_symb
-    _, bps = ofdm.constellation_func(cfg.Constellation)
-    b_sym = (cfg.Nfft + cfg.T_guard) * 8 + 2 * len(cfg.dataCarriers) * bps / 8 + len(cfg.pilotCarriers) * 8 / cfg.N_symb
-    res = {"config": "C5", "Nfft": cfg.Nfft, "frames": F, "dtype": "f32"}
-    for name, env in (("split", None), ("generic_single_kernel", "1")):
-        if env:
-            os.environ["OFDM_CHAIN_GENERIC"] = env
-        else:
-            os.environ.pop("OFDM_CHAIN_GENERIC", None)
-        ms, out = timed(lambda: ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref), reps=5 if env is None else 2,
-                        warm=2 if env is None else 1)
-        r = {"ms": ms, "sym_per_s": nsym / ms * 1e3, "hbm_frac": b_sym * nsym / (ms * 1e-3) / 1e9 / HBM,
-             "BER": float(out["errors"].sum().item()) / (F * data["bits"].shape[1])}
-        if env is None:
-            plan.set_timing(True)
-            k = []
-            for _ in range(5):
-                ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=ref)
-                k.append(plan.last_kernel_ms())
-            plan.set_timing(False)
-            k = np.mean(np.array(k), axis=0)
-            r["kernels_ms"] = {"demod_keep+pilot_ls": float(k[0]), "omp_batch_kernel": float(k[1]),
-                               "eq_demap_kernel": float(k[2])}
-        res[name] = r
-    os.environ.pop("OFDM_CHAIN_GENERIC", None)
-    return res
+    r = c5_batched(generic=True)
+    r["config"] = "C5"
+    return r
+
+
+def c2_quick(N_symb=100_000):
+    """BASELINE config 2: Nfft 1024, 16QAM, 100 k symbols through OFDM_modulator and OFDM_demodulator (+ payload / demapping)."""
+    Nfft, Tg, N_carrier, const = 1024, 128, 400, "16QAM"
+    _, pil, dat = dc.layout_percent(Nfft, N_carrier, 25, tail=2)
+    d, bps = ofdm.constellation_func(const)
+    bits = torch.from_numpy(dc.synthetic_bits(N_symb * len(dat) * bps, 2)).to(dev)
+    iq, pad = ofdm.mapping(bits, const, precision="fp32")
+    X = ofdm.OFDM_map_carriers(iq, N_symb, Nfft, dat, pil, 2 * float(np.max(np.abs(d))))
+    C = 8
+    ms_mod, tx = timed(lambda: ofdm.OFDM_modulator(X, Tg), reps=10)
+    ms_dem, Xr = timed(lambda: ofdm.OFDM_demodulator(tx, Tg), reps=10)
+    ms_bits, out = timed(lambda: ofdm.demapping(pad, ofdm.get_payload(Xr, dat), const), reps=5)
+    return {"workload": "C2: Nfft=1024 Tg=128 16QAM, 100k symbols, batched IFFT + CP / strip CP + FFT (per-function entries)",
+            "symbols": N_symb, "ms": ms_mod + ms_dem, "sym_per_s": N_symb / (ms_mod + ms_dem) * 1e3,
+            "kernels_ms": {"OFDM_modulator": ms_mod, "OFDM_demodulator": ms_dem, "get_payload+demapping": ms_bits},
+            "roofline": {"bound": "hbm", "peak": HBM, "unit": "GB/s",
+                         "OFDM_modulator": {"bytes_per_symbol": (2 * Nfft + Tg) * C,
+                                            "frac": (2 * Nfft + Tg) * C * N_symb / (ms_mod * 1e-3) / 1e9 / HBM},
+                         "OFDM_demodulator": {"bytes_per_symbol": 2 * Nfft * C,
+                                              "frac": 2 * Nfft * C * N_symb / (ms_dem * 1e-3) / 1e9 / HBM},
+                         "achieved": (4 * Nfft + Tg) * C * N_symb / ((ms_mod + ms_dem) * 1e-3) / 1e9,
+                         "frac": (4 * Nfft + Tg) * C * N_symb / ((ms_mod + ms_dem) * 1e-3) / 1e9 / HBM,
+                         "basis": "X read + guarded signal written (modulator), useful part read + X written (demodulator): each array once"},
+            "ber": float(ofdm.BER_func(bits, out))}
+
+
+def secondary_all():
+    """C2..C5 for bench.py's `secondary` key: about 10 s of GPU work, most of it frame generation."""
+    ofdm.init(0)
+    out = {}
+    for name, fn in (("C2", c2_quick), ("C3", c3_batched), ("C4", c4_batched), ("C5", c5_batched)):
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        out[name] = fn()
+        out[name]["wall_s"] = time.perf_counter() - t0
+    return out
 
 
 if __name__ == "__main__":
+    ofdm.init(0)
     which = sys.argv[1:] or ["C2", "C3", "C4", "C5"]
     for name in which:
         r = {"C2": c2, "C3": c3, "C4": c4, "C5": c5}[name]()
