@@ -778,14 +778,15 @@ def pilot_layout_comb(N_carrier, comb):
 # ----------------------------------------------------------------------------
 
 def rx_chain_task5(rx_frames, Nfft, T_guard, N_carrier, pilotCarriers, dataCarriers, pilotValues_col,
-                   K, dominant_taps, Constellation, ref_bits=None, Register=None):
+                   K, dominant_taps, Constellation, ref_bits=None, Register=None, want_iq=False):
     """Full Task-5 RX per frame: demod -> OMP (symbol 1) -> equalise -> payload -> demap -> BER.
 
     Call order of T5/Task5_part2.m:169-193,:272,:279-303 with Y formed as
     RX(pilots,1)./pilotValues(:,1) (:190) and S from T5/Main_model_Task_5.m:182-190.
 
     rx_frames : complex [(Nfft+Tg)*S, F]  (one column per frame, S symbols each)
-    returns dict(bits=[F, Nd*S*bps] uint8, errors=[F] int64, H=[F, N_carrier], index=list)
+    returns dict(bits=[F, Nd*S*bps] uint8, errors=[F] int64, H=[F, N_carrier], index=list
+                 [, iq=[F, Nd*S] the equalised payload points handed to demapping, want_iq=True])
     """
     rx = np.asarray(rx_frames)
     if rx.ndim == 1:
@@ -802,6 +803,7 @@ def rx_chain_task5(rx_frames, Nfft, T_guard, N_carrier, pilotCarriers, dataCarri
     errors = np.zeros(F, dtype=np.int64)
     Hs = np.zeros((F, N_carrier), dtype=np.complex128)
     picks = []
+    iqs = np.zeros((F, nd * S_sym), dtype=np.complex128) if want_iq else None
     for f in range(F):
         Xf = OFDM_demodulator(rx[:, f].reshape((L, S_sym), order="F"), T_guard)
         Yp = Xf[pc, 0] / pv
@@ -811,11 +813,16 @@ def rx_chain_task5(rx_frames, Nfft, T_guard, N_carrier, pilotCarriers, dataCarri
         eq = equalize_signal(Xf, H_omp, N_carrier)
         iq = get_payload(eq, dataCarriers).ravel(order="F")
         bits[f] = demapping(-1, iq, Constellation)
+        if want_iq:
+            iqs[f] = iq
         if Register is not None:                                   # T5/Main_model_Task_5.m:257-274, register reset per frame
             bits[f] = DeScrambler_fast(Register, bits[f])[0]
         if ref_bits is not None:
             errors[f] = np.count_nonzero(bits[f] != np.asarray(ref_bits)[f])
-    return dict(bits=bits, errors=errors, H=Hs, index=picks)
+    out = dict(bits=bits, errors=errors, H=Hs, index=picks)
+    if want_iq:
+        out["iq"] = iqs
+    return out
 
 
 # ----------------------------------------------------------------------------

@@ -59,7 +59,11 @@ def test_bench_launches_its_own_ranks():
     of 1 rank x 1024, so the per-frame error digest is the same."""
     two = _bench("--gpus", "2", "--backend", "gloo", "--force-device", "0", "--steps", "5", "--warmup", "2",
                  "--frames", "512", "--no-cpu")
-    one = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--frames", "1024", "--no-cpu")
+    one = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--frames", "1024", "--no-cpu", "--no-secondary",
+                 "--f64-steps", "3")
+    # the single-GPU line carries the reference-precision leg (fp64 plan, the same chain entry) and the environment in force
+    assert one["f64"]["dtype"] == "f64" and one["f64"]["value"] > 0 and 0 < one["f64"]["roofline"]["frac"] < 1
+    assert isinstance(one["env"], dict) and "f64" not in two
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["steps"] == 5
     assert two["frame_errors"] == one["frame_errors"] and one["frame_errors"]["frames"] == 1024
     assert two["config"]["symbols_per_step"] == one["config"]["symbols_per_step"] == 1024 * 14
