@@ -42,29 +42,15 @@ template <typename A> __device__ __forceinline__ acf4<A> acf_shfl_up(acf4<A> v, 
 }
 template <typename T> inline size_t acf_lds_bytes(int W) { return sizeof(acf4<T>) * (size_t)(ACF_TILE + W + 1); }
 
-template <typename T>
-__global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
-                                                          cx<T>* __restrict__ rho, int64_t n_out, int64_t rho_stride = 0,
-                                                          const int32_t* __restrict__ flist = nullptr,
-                                                          const int32_t* __restrict__ fcount = nullptr) {
-  // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out).  With a frame list
-  // (the frames a prefix of rho did not settle) grid.y strides over the list instead: a launch over an empty list costs
-  // a few hundred idle workgroups, not one per (tile, frame) -- that alone was 60 us per 1024 frames.
+// One tile of ACF_TILE outputs starting at n0 of one stream x: emit(i, rho) for i < n_here.  All ACF_THREADS threads call it;
+// S = the dynamic LDS table, wtot = ACF_THREADS / 64 entries of static LDS.  Ends with the table still valid (the caller
+// synchronises before the next tile overwrites it).
+template <typename T, typename Emit>
+__device__ __forceinline__ void acf_tile(const cx<T>* __restrict__ x, int64_t n0, int n_here, int W, int nfft,
+                                         acf4<T>* __restrict__ S, acf4<T>* __restrict__ wtot, Emit emit) {
   using A = T;
   using acc = acf4<A>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char acf_smem[];
-  acc* const S = (acc*)acf_smem;                     // [ACF_TILE + W + 1] exclusive prefix: S[i] = sum_{m<i}
-  __shared__ acc wtot[ACF_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const cx<T>* const x_all = x;
-  cx<T>* const rho_all = rho;
-  const int n_list = flist ? *fcount : 1;
-  for (int li = flist ? (int)blockIdx.y : 0; li < n_list; li += flist ? (int)gridDim.y : 1) {
-  const int64_t fr = flist ? (int64_t)flist[li] : (int64_t)blockIdx.y;
-  x = x_all + fr * len;
-  rho = rho_all + fr * (rho_stride ? rho_stride : n_out);
-  const int64_t n0 = (int64_t)blockIdx.x * ACF_TILE;
-  const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
   const int m_cnt = n_here + W - 1;                  // elements needed: m = n0 .. n0+n_here+W-2
   // (1) every thread forms the products of its own run of E consecutive elements and their inclusive prefix in
   //     registers (a wavefront still reads one contiguous span of x; the lines are reused across the run) ...
@@ -110,27 +96,116 @@ __global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restric
     const A den = sqrt(e1 * e2);                     // AutoCorrFunction.m:6
     if constexpr (sizeof(A) == 4) {
       const A inv = A(1) / den;
-      rho[n0 + i] = mk<T>(pr * inv, pi * inv);
+      emit(i, mk<T>(pr * inv, pi * inv));
     } else {
-      rho[n0 + i] = mk<T>((T)(pr / den), (T)(pi / den));
+      emit(i, mk<T>((T)(pr / den), (T)(pi / den)));
     }
   }
-  __syncthreads();                                   // S / wtot are reused by the next listed frame
+}
+
+template <typename T>
+__global__ __launch_bounds__(ACF_THREADS) void acf_kernel(const cx<T>* __restrict__ x, int64_t len, int W, int nfft,
+                                                          cx<T>* __restrict__ rho, int64_t n_out, int64_t rho_stride = 0) {
+  // batched callers: grid.y = frame (one stream per frame); rho rows rho_stride apart (0: n_out)
+  using acc = acf4<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char acf_smem[];
+  acc* const S = (acc*)acf_smem;                     // [ACF_TILE + W + 1] exclusive prefix: S[i] = sum_{m<i}
+  __shared__ acc wtot[ACF_THREADS / 64];
+  const int64_t fr = blockIdx.y;
+  x += fr * len;
+  rho += fr * (rho_stride ? rho_stride : n_out);
+  const int64_t n0 = (int64_t)blockIdx.x * ACF_TILE;
+  const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
+  cx<T>* const dst = rho + n0;
+  acf_tile<T>(x, n0, n_here, W, nfft, S, wtot, [dst](int i, cx<T> r) { dst[i] = r; });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched receiver (ofdm_rx_chain_task4): AutoCorrFunction.m:3-24 for one frame per workgroup WITHOUT the curve -- the
+// receiver needs TgPosition and AutoCorr(TgPosition) only (T4/Main_model_Task_4.m:278-303).  The tiles of acf_tile are
+// walked in order (so every rho value is bit-identical to acf_kernel's), each tile's rho stays in LDS, and the search of
+// :10-20 -- first index > WidthWindow above the threshold (f), first one below after it (g), first one above after that
+// (h: a second run exists) -- advances through the tile as a three-state machine; the walk stops at h (a symbol and a
+// half into the frame on average) or at the end of the stream (the catch branch, TgPosition = 65).  Replaces five
+// launches (rho of a three-symbol prefix -> plateau search -> list of unresolved frames -> rho of those over the whole
+// stream -> search again -> per-frame scalars) and the 0.5 GB round trip of the prefix curve.
+//   tg[f] = TgPosition, fo[f] = -angle(AutoCorr(TgPosition)) / (2 pi)  (:27), status[f] = 0 / 1 (catch branch) / -2 (index error at :27)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(ACF_THREADS) void t4_acf_search_kernel(const cx<T>* __restrict__ x_all, int64_t len, int W, int nfft,
+                                                                    int64_t n_out, double thr, int64_t* __restrict__ tg,
+                                                                    double* __restrict__ fo, int32_t* __restrict__ status) {
+  using acc = acf4<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char acf_smem[];
+  acc* const S = (acc*)acf_smem;
+  cx<T>* const rt = (cx<T>*)(S + ACF_TILE + W + 1);  // rho of the current tile
+  __shared__ acc wtot[ACF_THREADS / 64];
+  __shared__ int wmin[ACF_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t fr = blockIdx.x;
+  const cx<T>* const x = x_all + fr * len;
+  auto tile = [&](int64_t n0) {
+    const int n_here = (int)((n_out - n0 < ACF_TILE) ? (n_out - n0) : ACF_TILE);
+    acf_tile<T>(x, n0, n_here, W, nfft, S, wtot, [rt](int i, cx<T> r) { rt[i] = r; });
+    __syncthreads();
+    return n_here;
+  };
+  // the smallest i in [lo, n_here) of the tile in LDS whose |rho| is above (want_above) / not above the threshold, or -1
+  auto first_in_tile = [&](int lo, int n_here, bool want_above) -> int {
+    int best = 0x7fffffff;
+    for (int i = lo + tid; i < n_here; i += ACF_THREADS) {        // ascending per thread: its first hit is its smallest
+      const cx<T> v = rt[i];
+      const bool ab = sqrt((double)v.x * v.x + (double)v.y * v.y) > thr;
+      if (ab == want_above) { best = i; break; }
+    }
+    for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+    if (lane == 0) wmin[wid] = best;
+    __syncthreads();
+    int r = wmin[0];
+    for (int w = 1; w < ACF_THREADS / 64; ++w) r = min(r, wmin[w]);
+    __syncthreads();
+    return r == 0x7fffffff ? -1 : r;
+  };
+  int stage = 0;                                      // 0: looking for f, 1: g, 2: h, 3: found
+  int64_t from = W, f0 = -1, g0 = -1;                 // 1-based index idx = i + 1 must be > W  <=>  i >= W
+  int64_t cur_n0 = -1;
+  for (int64_t n0 = (from / ACF_TILE) * ACF_TILE; n0 < n_out && stage < 3; n0 += ACF_TILE) {
+    const int n_here = tile(n0);
+    cur_n0 = n0;
+    while (stage < 3) {
+      const int lo = from > n0 ? (int)(from - n0) : 0;
+      const int r = lo < n_here ? first_in_tile(lo, n_here, stage != 1) : -1;
+      if (r < 0) break;
+      if (stage == 0) f0 = n0 + r; else if (stage == 1) g0 = n0 + r;
+      from = n0 + r + 1;
+      ++stage;
+    }
+  }
+  const int ok = stage == 3;
+  const int64_t pos = ok ? ((f0 + 1) + (g0 - 1 + 1)) / 2 : 65;   // :20 floor of the mean of the run's 1-based ends; :23
+  double vr = NAN, vi = NAN;
+  if (pos >= 1 && pos <= n_out) {
+    const int64_t pn0 = ((pos - 1) / ACF_TILE) * ACF_TILE;
+    if (pn0 != cur_n0) tile(pn0);                    // the plateau's tile is no longer (or was never) the one in LDS
+    const cx<T> v = rt[pos - 1 - pn0];
+    vr = (double)v.x; vi = (double)v.y;
+  }
+  if (tid == 0) {
+    tg[fr] = pos;
+    fo[fr] = -atan2(vi, vr) / (2.0 * M_PI);
+    status[fr] = pos > n_out ? -2 : (ok ? 0 : 1);
   }
 }
+
+template <typename T> inline size_t acf_search_lds_bytes(int W) { return acf_lds_bytes<T>(W) + sizeof(cx<T>) * ACF_TILE; }
 
 // dynamic LDS beyond 64 KB (double table at WidthWindow = 1024) has to be allowed for the kernel (per device: set on every call)
 template <typename T>
 static int acf_prepare() {
   OFDM_HIP(hipFuncSetAttribute((const void*)acf_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acf_lds_bytes<T>(ACF_MAXW)));
+  OFDM_HIP(hipFuncSetAttribute((const void*)t4_acf_search_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)acf_search_lds_bytes<T>(ACF_MAXW)));
   return OFDM_OK;
-}
-
-// frames whose plateau search did not succeed on the prefix of rho (res[2 f + 1] == 0), in any order
-__global__ void t4_unresolved_kernel(const int64_t* __restrict__ res, int64_t n_frames, int32_t* __restrict__ flist,
-                                     int32_t* __restrict__ fcount) {
-  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < n_frames && !res[2 * f + 1]) flist[atomicAdd(fcount, 1)] = (int32_t)f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -161,12 +236,10 @@ __device__ int64_t first_index_where(const cx<T>* __restrict__ rho, int64_t from
 template <typename T>
 __global__ __launch_bounds__(PLAT_THREADS) void acf_plateau_kernel(const cx<T>* __restrict__ rho, int64_t n, int W,
                                                                    double thr, int64_t* __restrict__ out,
-                                                                   double* __restrict__ outv, int64_t rho_stride = 0,
-                                                                   int skip_resolved = 0) {
+                                                                   double* __restrict__ outv, int64_t rho_stride = 0) {
   rho += (int64_t)blockIdx.x * (rho_stride ? rho_stride : n);   // grid.x = frame
   out += 2 * blockIdx.x;
   outv += 2 * blockIdx.x;
-  if (skip_resolved && out[1]) return;               // decided on a prefix of rho: the full scan finds the same runs
   __shared__ int64_t sh;
   auto above = [thr](cx<T> v) { return sqrt((double)v.x * v.x + (double)v.y * v.y) > thr; };
   auto below = [thr](cx<T> v) { return !(sqrt((double)v.x * v.x + (double)v.y * v.y) > thr); };
@@ -250,14 +323,20 @@ __device__ __forceinline__ double tau_of(double ar, double ai, double br, double
 // each angle is formed once, and a frame of 6700 pilots takes 7 trips instead of 27.
 constexpr int FS_U = 4;
 
+// scratch of the two reductions (static LDS of the calling kernel)
+struct FsScratch {
+  int wcnt[FS_THREADS / 64];
+  double wsum[FS_THREADS / 64];
+  int64_t wn[FS_THREADS / 64];
+  double result;
+};
+
+// the residual timing estimate tau of one frame, returned to every thread of the FS_THREADS-thread workgroup
 template <typename T>
-__global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, double deltak, int variant,
-                                                              double* __restrict__ out /* [0]=tau */) {
-  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
-  out += 2 * blockIdx.x;
-  __shared__ int wcnt[FS_THREADS / 64];
-  __shared__ double wsum[FS_THREADS / 64];
-  __shared__ int64_t wn[FS_THREADS / 64];
+__device__ double fine_tau_body(const PilotView<T>& pv, double deltak, int variant, FsScratch& sc) {
+  int (&wcnt)[FS_THREADS / 64] = sc.wcnt;
+  double (&wsum)[FS_THREADS / 64] = sc.wsum;
+  int64_t (&wn)[FS_THREADS / 64] = sc.wn;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double inv = 1.0 / (2.0 * M_PI * deltak);
   const unsigned M = (unsigned)pv.M;
@@ -326,20 +405,45 @@ __global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, d
   if (tid == 0) {
     double s = 0; int64_t n = 0;
     for (int w = 0; w < FS_THREADS / 64; ++w) { s += wsum[w]; n += wn[w]; }
-    out[0] = n > 0 ? s / (double)n : NAN;                        // mean([]) = NaN
+    sc.result = n > 0 ? s / (double)n : NAN;                     // mean([]) = NaN
   }
+  __syncthreads();
+  const double r = sc.result;
+  __syncthreads();
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(FS_THREADS) void fine_tau_kernel(PilotView<T> pv, double deltak, int variant,
+                                                              double* __restrict__ out /* [0]=tau */) {
+  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
+  __shared__ FsScratch sc;
+  const double tau = fine_tau_body<T>(pv, deltak, variant, sc);
+  if (threadIdx.x == 0) out[2 * blockIdx.x] = tau;
 }
 
 // fine_sync.m:32-37 -- common phase after the (optional) timing derotation; out[1] = phase_shift
+// rotation exp(-2 pi j tau k) of pilot row k as (cos, sin): the arithmetic of fine_phase_body's per-entry form
 template <typename T>
-__global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv, int time_desync,
-                                                                double* __restrict__ out) {
-  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
-  out += 2 * blockIdx.x;
-  __shared__ double wsum[FS_THREADS / 64];
-  __shared__ int64_t wn[FS_THREADS / 64];
+__device__ __forceinline__ void fine_rot(double tau, int k, double& cs, double& sn) {
+  const double t = tau * (double)k;
+  if constexpr (sizeof(T) == 4) {                                  // throughput mode: phase reduced in double, sine / cosine in float
+    float fs, fc;
+    sincospif(2.0f * (float)(t - floor(t)), &fs, &fc);
+    sn = fs; cs = fc;
+  } else {
+    sincospi(2.0 * (t - floor(t)), &sn, &cs);
+  }
+}
+
+// rot_tab (optional, [np] (cos, sin) of fine_rot per pilot row): the rotation depends on the pilot row only, a caller that
+// holds a whole frame computes it once per row instead of once per (row, symbol) -- same values
+template <typename T>
+__device__ double fine_phase_body(const PilotView<T>& pv, int time_desync, double tau, FsScratch& sc,
+                                  const double2* rot_tab = nullptr) {
+  double (&wsum)[FS_THREADS / 64] = sc.wsum;
+  int64_t (&wn)[FS_THREADS / 64] = sc.wn;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const double tau = out[0];
   const unsigned M = (unsigned)pv.M;
   double sum = 0.0;
   int64_t cnt = 0;
@@ -357,16 +461,9 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
       if (i < M) {
         if (time_desync) {
           // rx' = rx * exp(+2 pi j tau k)  =>  q' = q * exp(-2 pi j tau k)   (fine_sync.m:25-27, nn_exp')
-          const int k = pv.pc0[i % (unsigned)pv.np];
-          const double t = tau * (double)k;
           double sn, cs;
-          if constexpr (sizeof(T) == 4) {                          // throughput mode: phase reduced in double, sine / cosine in float
-            float fs, fc;
-            sincospif(2.0f * (float)(t - floor(t)), &fs, &fc);
-            sn = fs; cs = fc;
-          } else {
-            sincospi(2.0 * (t - floor(t)), &sn, &cs);
-          }
+          if (rot_tab) { const double2 r = rot_tab[i % (unsigned)pv.np]; cs = r.x; sn = r.y; }
+          else fine_rot<T>(tau, pv.pc0[i % (unsigned)pv.np], cs, sn);
           const double r2 = qr[u] * cs + qi[u] * sn, i2 = qi[u] * cs - qr[u] * sn;
           qr[u] = r2; qi[u] = i2;
         }
@@ -381,8 +478,21 @@ __global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv,
   if (tid == 0) {
     double s = 0; int64_t n = 0;
     for (int w = 0; w < FS_THREADS / 64; ++w) { s += wsum[w]; n += wn[w]; }
-    out[1] = n > 0 ? s / (double)n : NAN;
+    sc.result = n > 0 ? s / (double)n : NAN;
   }
+  __syncthreads();
+  const double r = sc.result;
+  __syncthreads();
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(FS_THREADS) void fine_phase_kernel(PilotView<T> pv, int time_desync,
+                                                                double* __restrict__ out) {
+  pv.rx += (int64_t)blockIdx.x * pv.rx_fstride;      // grid.x = frame
+  __shared__ FsScratch sc;
+  const double ph = fine_phase_body<T>(pv, time_desync, out[2 * blockIdx.x], sc);
+  if (threadIdx.x == 0) out[2 * blockIdx.x + 1] = ph;
 }
 
 // fine_sync.m:23-29,:39-43 -- apply both corrections in one pass
@@ -717,6 +827,77 @@ __global__ void t4_mean_pilots_kernel(const cx<T>* __restrict__ X, const cx<T>* 
   hp[f * np + p] = mk<T>((T)(ar / (double)n_symb), (T)(ai / (double)n_symb));
 }
 
+// fine_sync's two estimates (T4/fine_sync.m:10-20, :32-37) and the pilot means of estimate_channel.m:6 of one frame in ONE
+// workgroup: the frame's pilot rows (compact, written by the demodulator) come from HBM once and from L2 after that, and the
+// rotation of fine_sync.m:24-27 is formed once per pilot row instead of once per (row, symbol) -- they used to be three
+// launches, each one sweep through HBM.  The arithmetic is the bodies of fine_tau_kernel /
+// fine_phase_kernel / t4_mean_pilots_kernel unchanged.  sync == 0: only the means (no estimates, no rotation).
+template <typename T>
+__global__ __launch_bounds__(FS_THREADS) void t4_fine_est_kernel(const cx<T>* __restrict__ xp, const cx<T>* __restrict__ tx,
+                                                                 const int32_t* __restrict__ pc0, int nfft, int np, int n_symb,
+                                                                 double deltak, int sync, int time_desync, int freq_desync,
+                                                                 int mp_desync, double* __restrict__ est, cx<T>* __restrict__ hp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
+  double2* const rot = (double2*)fe_smem;            // [np] rotation of fine_sync.m:24-27 per pilot row
+  __shared__ FsScratch sc;
+  const int64_t f = blockIdx.x;
+  const int M = np * n_symb;
+  // the frame's pilot rows [np x n_symb] stay where the demodulator wrote them: 48 KB per frame at the C3 geometry, read three
+  // times by this workgroup -- from L2 after the first touch.  (Staging them in LDS was slower: 3 instead of 8 resident
+  // workgroups per CU and flat loads in the shared reduction bodies, 0.45 against 0.35 ms per 4096 frames.)
+  const cx<T>* const lp = xp + f * (int64_t)M;
+  double tau = 0.0, ph = 0.0;
+  if (sync) {
+    PilotView<T> pv{lp, tx, pc0, nfft, np, (int64_t)M, 0, 1};
+    tau = fine_tau_body<T>(pv, deltak, 1 /* T4 variant */, sc);
+    if (time_desync) {
+      for (int p = threadIdx.x; p < np; p += FS_THREADS) {
+        double cs, sn;
+        fine_rot<T>(tau, pc0[p], cs, sn);
+        rot[p] = make_double2(cs, sn);
+      }
+      __syncthreads();
+    }
+    ph = fine_phase_body<T>(pv, time_desync, tau, sc, time_desync ? rot : nullptr);
+    if (threadIdx.x == 0) { est[2 * f] = tau; est[2 * f + 1] = ph; }
+  }
+  if (!mp_desync) return;
+  for (int p = threadIdx.x; p < np; p += FS_THREADS) {           // t4_mean_pilots_kernel for pilot p
+    double rc = 1.0, rs = 0.0;
+    if (sync) {
+      double psn = 0.0, pcs = 1.0, cs = 1.0, sn = 0.0;
+      if (freq_desync) sincos(ph, &psn, &pcs);
+      if (time_desync) {
+        const double t = tau * (double)pc0[p];
+        sincospi(2.0 * (t - floor(t)), &sn, &cs);
+      }
+      rc = cs * pcs - sn * psn;
+      rs = sn * pcs + cs * psn;
+    }
+    double ar = 0, ai = 0;
+    for (int s0 = 0; s0 < n_symb; s0 += 10) {                     // ten strided samples requested together
+      cx<T> xs[10], ts[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const int s = s0 + u < n_symb ? s0 + u : n_symb - 1;
+        xs[u] = lp[s * np + p];
+        ts[u] = tx[s * np + p];
+      }
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        if (s0 + u < n_symb) {
+          cx<T> xv = xs[u];
+          if (sync) xv = mk<T>((T)((double)xv.x * rc - (double)xv.y * rs), (T)((double)xv.x * rs + (double)xv.y * rc));
+          const cx<T> q = cdiv(xv, ts[u]);
+          ar += (double)q.x;
+          ai += (double)q.y;
+        }
+      }
+    }
+    hp[f * np + p] = mk<T>((T)(ar / (double)n_symb), (T)(ai / (double)n_symb));
+  }
+}
+
 // H(1..N_carrier) = W * Hp for T4_FT frames per workgroup: a weight is read once and used for all of them (one frame per
 // workgroup re-read the 429 KB operator from L2 for every frame: 70 us per 1024 frames); the pilot means are wave-uniform
 // reads.  double accumulation: the not-a-knot weights alternate in sign.
@@ -760,9 +941,8 @@ __global__ __launch_bounds__(128) void t4_apply_operator_kernel(const T* __restr
 }
 
 __global__ void t4_init_kernel(int32_t* __restrict__ stat, int64_t* __restrict__ tg, double* __restrict__ fo, int32_t* __restrict__ ifo,
-                               int32_t* __restrict__ fcount, int64_t n_frames) {
+                               int64_t n_frames) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f == 0) *fcount = 0;
   if (f < n_frames) { stat[f] = 0; tg[f] = 0; fo[f] = 0.0; ifo[f] = 0; }
 }
 
@@ -790,11 +970,11 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   const size_t o_est = reserve(sizeof(double) * 2 * F), o_hp = reserve(sizeof(cx<T>) * (size_t)np * F);
   const size_t o_H = reserve(sizeof(cx<T>) * (size_t)nc * F);
   const size_t o_Xp = reserve(sizeof(cx<T>) * (size_t)np * S * F);
-  const size_t o_rho = reserve(sync && n_out > 0 ? sizeof(cx<T>) * (size_t)n_out * F : 0);
+  const bool full_acf = getenv("OFDM_T4_FULL_ACF") != nullptr;       // the curve in HBM + the search over it (A/B, tests)
+  const size_t o_rho = reserve(sync && full_acf && n_out > 0 ? sizeof(cx<T>) * (size_t)n_out * F : 0);
   const size_t o_seg = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
   const size_t o_spec = reserve(freq_desync ? sizeof(cx<T>) * (size_t)N * F : 0);
   const size_t o_first = reserve(freq_desync ? sizeof(int64_t) * F : 0);
-  const size_t o_flist = reserve(sizeof(int32_t) * (F + 1));
   if (pl->ws_t4_bytes < need) {
     OFDM_HIP(hipStreamSynchronize(s));
     if (pl->ws_t4) { (void)hipFree(pl->ws_t4); pl->ws_t4 = nullptr; pl->ws_t4_bytes = 0; }
@@ -811,37 +991,26 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   pl->t4_timed = timed ? 1 : 0;
   auto mark = [&](int i) { if (timed) (void)hipEventRecord(pl->ev_t4[i], s); };
   mark(0);
-  // per-frame scalars and the unresolved-frame counter start at zero: one launch instead of five memsets (4.7 us each)
-  hipLaunchKernelGGL(t4_init_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, dstat, dtg, dfo, difo, (int32_t*)(arena + o_flist), F);
+  // per-frame scalars start at zero: one launch instead of four memsets (4.7 us each)
+  hipLaunchKernelGGL(t4_init_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, dstat, dtg, dfo, difo, F);
   if (sync) {
     OFDM_ARG(n_out > 0 && Tg >= 1 && Tg <= ACF_MAXW, "rx_chain_task4: frame shorter than T_guard + Nfft, or T_guard outside 1..%d", ACF_MAXW);
-    drho = arena + o_rho;
-    // The receiver only needs TgPosition and rho(TgPosition), and AutoCorrFunction.m:10-24 decides them on the first
-    // run above the threshold, its end and the first later sample above it: a prefix of three symbols settles nearly
-    // every frame.  Prefix = whole tiles, so its rho values are bit-identical to the full computation; frames it does
-    // not settle (ok = 0) are redone over the whole stream, the others leave that second pass at its first instruction.
-    const int64_t n_pref = std::min<int64_t>(n_out, ((3 * (int64_t)(N + Tg) + ACF_TILE - 1) / ACF_TILE) * ACF_TILE);
-    const bool two_pass = n_pref < n_out && !getenv("OFDM_T4_FULL_ACF");
     OFDM_TRY(acf_prepare<T>());
-    if (two_pass) {
-      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_pref, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s, (const cx<T>*)drx, len, Tg,
-                         N, (cx<T>*)drho, n_pref, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
-      hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_pref, Tg, 0.77,
-                         (int64_t*)dres, (double*)dresv, n_out, 0);
-    }
-    if (two_pass) {
-      int32_t* dfl = (int32_t*)(arena + o_flist);                // [0] = count, [1..] = frames still to do
-      hipLaunchKernelGGL(t4_unresolved_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, F, dfl + 1, dfl);
-      hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)std::min<int64_t>(F, 8)), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s,
-                         (const cx<T>*)drx, len, Tg, N, (cx<T>*)drho, n_out, n_out, (const int32_t*)(dfl + 1), (const int32_t*)dfl);
+    if (!full_acf) {
+      // one workgroup per frame walks the tiles of the autocorrelation until the search of AutoCorrFunction.m:10-20 is
+      // decided (t4_acf_search_kernel): no curve in HBM, one launch
+      hipLaunchKernelGGL(t4_acf_search_kernel<T>, dim3((unsigned)F), dim3(ACF_THREADS), acf_search_lds_bytes<T>(Tg), s, (const cx<T>*)drx, len,
+                         Tg, N, n_out, 0.77, dtg, dfo, dstat);
     } else {
+      // OFDM_T4_FULL_ACF: the whole curve per frame, then the search over it (the kernels of ofdm_AutoCorrFunction)
+      drho = arena + o_rho;
       hipLaunchKernelGGL(acf_kernel<T>, dim3(cdiv_u(n_out, ACF_TILE), (unsigned)F), dim3(ACF_THREADS), acf_lds_bytes<T>(Tg), s, (const cx<T>*)drx, len, Tg,
-                         N, (cx<T>*)drho, n_out, n_out, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                         N, (cx<T>*)drho, n_out, n_out);
+      hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
+                         (int64_t*)dres, (double*)dresv, n_out);
+      hipLaunchKernelGGL(t4_scalars_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, (const double*)dresv, n_out,
+                         dtg, dfo, dstat, F);
     }
-    hipLaunchKernelGGL(acf_plateau_kernel<T>, dim3((unsigned)F), dim3(PLAT_THREADS), 0, s, (const cx<T>*)drho, n_out, Tg, 0.77,
-                       (int64_t*)dres, (double*)dresv, n_out, two_pass ? 1 : 0);
-    hipLaunchKernelGGL(t4_scalars_kernel, dim3(cdiv_u(F, 256)), dim3(256), 0, s, (const int64_t*)dres, (const double*)dresv, n_out,
-                       dtg, dfo, dstat, F);
     OFDM_TRY(check_launch("AutoCorrFunction stage"));
   }
   mark(1);
@@ -905,9 +1074,18 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     OFDM_HIP(hipMemcpy(pl->d_t4_w, Wt.data(), sizeof(T) * Wt.size(), hipMemcpyHostToDevice));
   }
   const void *dtx = pl->d_t4_tx, *dW = pl->d_t4_w;
-  if (sync) {
-    OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
-    const double deltak = (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0];       // fine_sync.m:6
+  if (sync) OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
+  const double deltak = np >= 2 ? (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0] : 1.0;      // fine_sync.m:6
+  // direct form: fine_sync's two estimates and the pilot means in ONE launch on the frame's compact pilot rows held in LDS
+  const size_t fe_lds = sizeof(double2) * (size_t)np;
+  const bool fused_est = direct && fe_lds <= 48 * 1024 && (sync || mp_desync) && !getenv("OFDM_T4_UNFUSED_SYNC");
+  if (fused_est) {
+    OFDM_HIP(hipFuncSetAttribute((const void*)t4_fine_est_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe_lds));
+    hipLaunchKernelGGL(t4_fine_est_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), fe_lds, s, (const cx<T>*)dXp, (const cx<T>*)dtx,
+                       (const int32_t*)pl->d_pc0, N, np, S, deltak, sync ? 1 : 0, time_desync, freq_desync, mp_desync, (double*)dest,
+                       (cx<T>*)dhp);
+    OFDM_TRY(check_launch("t4_fine_est_kernel"));
+  } else if (sync) {
     PilotView<T> pv{direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, N, np, (int64_t)np * S,
                     direct ? (int64_t)np * S : (int64_t)N * S, direct ? 1 : 0};
     hipLaunchKernelGGL(fine_tau_kernel<T>, dim3((unsigned)F), dim3(FS_THREADS), 0, s, pv, deltak, 1 /* T4 variant */, (double*)dest);
@@ -920,9 +1098,10 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   }
   const double* lazy_rot = (sync && direct) ? (const double*)dest : nullptr;
   if (mp_desync) {
-    hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s,
-                       direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S,
-                       lazy_rot, time_desync, freq_desync, direct ? 1 : 0);
+    if (!fused_est)
+      hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s,
+                         direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S,
+                         lazy_rot, time_desync, freq_desync, direct ? 1 : 0);
     hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), sizeof(cx<T>) * np * T4_FT, s, (const T*)dW,
                        (const cx<T>*)dhp, (cx<T>*)dH, nc, np, F);
   } else {
