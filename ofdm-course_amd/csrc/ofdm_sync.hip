@@ -951,6 +951,11 @@ __global__ void t4_fill_ones_kernel(cx<T>* __restrict__ h, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) h[i] = mk<T>(1, 0);
 }
 
+// ofdm_t4_wave.hip
+bool t4_demod_wave_supported(int nfft, int n_keep, int np, bool f64);
+int t4_demod_wave_launch(const void* rx, void* X, const void* tw, int64_t len, int t_guard, int n_symb, int64_t F, int td, int fd,
+                         const int64_t* tg, const double* fo, const int32_t* ifo, int n_keep, void* xp, const void* prole, int np);
+
 template <typename T>
 static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desync, int freq_desync, int mp_desync,
                      void* dbits, const void* dref, void* derr, int64_t* dtg, double* dfo, int32_t* difo, int32_t* dstat,
@@ -1033,6 +1038,9 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     mark(2);
     const void* twd = nullptr;
     OFDM_TRY(get_twiddles(N, f64, &twd));
+    if (t4_demod_wave_supported(N, nc, np, f64)) {         // Nfft 2048, fp32, N_carrier <= 1024: one wavefront per symbol run
+      OFDM_TRY(t4_demod_wave_launch(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np));
+    } else
     switch (N / 512) {
       case 1: OFDM_TRY((t4_demod_launch<T, 1>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;
       case 2: OFDM_TRY((t4_demod_launch<T, 2>(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np))); break;

@@ -266,3 +266,46 @@ def test_batch_on_generated_frames_with_descrambler(ofdm, oracle, precision):
             assert np.count_nonzero(rb[f] != ref["bits"]) <= (0 if precision == "fp64" else 4)
             decoded += int(raw["errors"][f]) < 0.2 * nb
     assert decoded >= 1                                                # the reference's own pass criterion (BER < 0.2, T4:367)
+
+
+@pytest.mark.parametrize("flags", [(1, 1, 1), (1, 0, 1), (0, 1, 0), (0, 0, 0)])
+def test_batch_wave_demodulator_nfft2048_fp32(ofdm, monkeypatch, flags):
+    """t4_demod_wave_kernel (Nfft 2048, fp32, N_carrier <= 1024: one wavefront per symbol run, STO fix and merged CFO rotor at
+    the loads) against the per-function chain frame by frame, for symbol runs of 1, 3 and all 7 symbols (runs that end inside
+    a frame, cross-run prefetch, the blanked first symbol, the zero tail of a late TgPosition), and against the
+    four-wavefronts-per-symbol demodulator (OFDM_T4_NO_WAVE) on the same batch."""
+    from ofdm_course_amd import frames as fr
+    for v in ("OFDM_T4_STAGED", "OFDM_T4_NO_WAVE", "OFDM_T4_WAVE_SPC"):
+        monkeypatch.delenv(v, raising=False)
+    cfg_kw = dict(Nfft=2048, N_carrier=800, N_symb=7, const="64QAM")
+    nfr = 9
+    d = _frames(ofdm, cfg_kw, nfr, "fp32", seed=31)
+    K = int(np.ceil(800 / 6))
+    plan = ofdm.RxPlan(2048, d["Tg"], 7, 800, d["pil"], d["dat"], d["col"], K, 3, "64QAM", precision="fp32")
+    packed = fr.pack_bits(d["bits"])
+    outs = {}
+    for spc in ("1", "3", "7", "old"):
+        if spc == "old":
+            monkeypatch.setenv("OFDM_T4_NO_WAVE", "1")
+        else:
+            monkeypatch.setenv("OFDM_T4_WAVE_SPC", spc)
+        outs[spc] = ofdm.rx_chain_task4(plan, d["rx"], *flags, ref_bits_packed=packed, want_h=True)
+    monkeypatch.delenv("OFDM_T4_NO_WAVE", raising=False)
+    out = outs["3"]
+    nb = d["bits"].shape[1]
+    got_bits = fr.unpack_bits(np.asarray(out["bits"]), nb)
+    for spc in ("1", "7"):                                   # the run length changes nothing at all
+        assert np.array_equal(np.asarray(outs[spc]["bits"]), np.asarray(out["bits"]))
+        assert np.array_equal(np.asarray(outs[spc]["H"]), np.asarray(out["H"]), equal_nan=True)
+    old_bits = fr.unpack_bits(np.asarray(outs["old"]["bits"]), nb)
+    for f in range(nfr):
+        ref = _per_function(ofdm, d["rx"][:, f].copy(), d, cfg_kw, flags)
+        assert int(out["TgPosition"][f]) == ref["TgPosition"] and int(out["status"][f]) == ref["status"]
+        if ref["status"] >= 0:
+            assert int(out["IFO"][f]) == ref["IFO"]
+            assert np.count_nonzero(got_bits[f] != ref["bits"]) <= 4, f
+            assert np.count_nonzero(got_bits[f] != old_bits[f]) <= 4, f
+            if flags[2] and np.all(np.isfinite(ref["H"])):
+                assert rel_l2(np.asarray(out["H"])[:, f], ref["H"]) < 1e-4
+                assert rel_l2(np.asarray(out["H"])[:, f], np.asarray(outs["old"]["H"])[:, f]) < 2e-5
+        assert int(out["errors"][f]) == np.count_nonzero(got_bits[f] != d["bits"][f])
