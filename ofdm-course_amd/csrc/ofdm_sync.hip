@@ -953,6 +953,8 @@ __global__ void t4_fill_ones_kernel(cx<T>* __restrict__ h, int64_t n) {
 
 // ofdm_t4_wave.hip
 bool t4_demod_wave_supported(int nfft, int n_keep, int np, bool f64);
+int t4_ifo_wave_launch(const void* rx, const void* tw, int64_t len, int t_guard, int64_t F, int td, const int64_t* tg,
+                       const double* fo, int32_t* ifo_out, int32_t* status);
 int t4_demod_wave_launch(const void* rx, void* X, const void* tw, int64_t len, int t_guard, int n_symb, int64_t F, int td, int fd,
                          const int64_t* tg, const double* fo, const int32_t* ifo, int n_keep, void* xp, const void* prole, int np);
 
@@ -1025,7 +1027,12 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
   if (freq_desync) OFDM_ARG(len >= 2 * (int64_t)N, "rx_chain_task4: rx_signal(Nfft+1:2*Nfft) exceeds the frame");
   if (direct) {
     // no aligned / corrected copy of the batch: the IFO search reads its segment, the demodulator its samples, from rx
-    if (freq_desync) {
+    const void* twd = nullptr;
+    OFDM_TRY(get_twiddles(N, f64, &twd));
+    const bool wave = t4_demod_wave_supported(N, nc, np, f64);
+    if (freq_desync && wave) {                       // segment, spectrum and search of remove_IFO.m:5-8 in one launch
+      OFDM_TRY(t4_ifo_wave_launch(drx, twd, len, Tg, F, td_eff, dtg, dfo, difo, dstat));
+    } else if (freq_desync) {
       dseg = arena + o_seg; dspec = arena + o_spec; dfirst = arena + o_first;
       hipLaunchKernelGGL(t4_segment_direct_kernel<T>, dim3(cdiv_u(N, 256), (unsigned)F), dim3(256), 0, s, (const cx<T>*)drx, (cx<T>*)dseg,
                          len, N + Tg, N, td_eff, (const int64_t*)dtg, (const double*)dfo);
@@ -1036,9 +1043,7 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
       OFDM_TRY(check_launch("remove_IFO stage"));
     }
     mark(2);
-    const void* twd = nullptr;
-    OFDM_TRY(get_twiddles(N, f64, &twd));
-    if (t4_demod_wave_supported(N, nc, np, f64)) {         // Nfft 2048, fp32, N_carrier <= 1024: one wavefront per symbol run
+    if (wave) {         // Nfft 2048, fp32, N_carrier <= 1024: one wavefront per symbol run
       OFDM_TRY(t4_demod_wave_launch(drx, dX, twd, len, Tg, S, F, td_eff, fd_eff, dtg, dfo, difo, nc, dXp, pl->d_prole, np));
     } else
     switch (N / 512) {

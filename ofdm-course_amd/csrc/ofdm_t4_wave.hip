@@ -272,6 +272,129 @@ __global__ __launch_bounds__(64 * T4W_WPB, 3) void t4_demod_wave_kernel(const cx
   }
 }
 
+// remove_IFO.m:5-8 of the batched receiver in ONE launch, one wavefront per frame: the segment rx_signal(Nfft+1 : 2 Nfft) taken
+// from rx through the STO fix (t4_raw) and add_CFO(., -FreqOffset) (one rotor per sample, the demodulator's form), its
+// 2048-point spectrum on the transform above with all eight outputs of the last radix-8, and IFO = the first bin whose
+// magnitude exceeds 0.77 (:6-8) -- a minimum over the lane's 32 bins, then across the wavefront.  ifo_out[f] = bin or -1
+// (no line: status -1, the script would stop at inds(1)).  Replaces segment copy -> FFT launch -> search -> finalize.
+__global__ __launch_bounds__(64 * T4W_WPB) void t4_ifo_wave_kernel(const cx<float>* __restrict__ rx, const cx<float>* __restrict__ tw,
+                                                                   int64_t len, int t_guard, int64_t n_frames, int time_desync,
+                                                                   const int64_t* __restrict__ tg, const double* __restrict__ fo,
+                                                                   double thr, int32_t* __restrict__ ifo_out,
+                                                                   int32_t* __restrict__ status) {
+  using T = float;
+  constexpr int N = T4W_N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lane8 = 8u * lane;
+  auto tw32_at = [&](int row) { return *(const cx<T>*)(smem + T4W_OFF_TW + 512 * row + lane8); };
+  auto twbl_at = [&](int row) { return *(const cx<T>*)(smem + T4W_OFF_TWB + 512 * row + lane8); };
+  {
+    cx<T>* const t32 = (cx<T>*)(smem + T4W_OFF_TW);
+    cx<T>* const tbl = (cx<T>*)(smem + T4W_OFF_TWB);
+    for (int i = threadIdx.x; i < 31 * 64; i += blockDim.x) t32[i] = tw[((i / 64 + 1) * (i & 63)) & (N - 1)];
+    for (int i = threadIdx.x; i < 7 * 64; i += blockDim.x) tbl[i] = tw[(i / 64 + 1) * (i & 7) * 32];
+  }
+  __syncthreads();
+  const unsigned wbase = T4W_OFF_WAVE + (unsigned)wave * T4W_WAVE_BYTES;
+  cx<T>* const t1w = (cx<T>*)(smem + wbase + lane8);
+  cx<T>* const t1r = (cx<T>*)(smem + wbase) + 72 * (lane >> 3) + (lane & 7);
+  cx<T>* const t2w = (cx<T>*)(smem + wbase) + 65 * (lane & 7) + 8 * (lane >> 3);
+  cx<T>* const t2r = (cx<T>*)(smem + wbase + lane8);
+  const int sym_len = N + t_guard;
+  const double inv = 1.0 / (double)N;
+  for (int64_t f = (int64_t)blockIdx.x * T4W_WPB + wave; f < n_frames; f += (int64_t)gridDim.x * T4W_WPB) {
+    const cx<T>* xf = rx + f * len;
+    const int64_t pos = time_desync ? tg[f] : 0;
+    const double cfo = -fo[f];
+    cx<T> v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int64_t i = (int64_t)N + lane + 64 * j;                   // stream index of rx_signal(Nfft + 1 + m)
+      if (!time_desync) v[j] = nt_load(xf + i);
+      else {
+        const int64_t i1 = i - sym_len;
+        v[j] = (i1 >= 0 && i1 + pos < len) ? nt_load(xf + i1 + pos) : mk<T>(0, 0);
+      }
+    }
+    // add_CFO(., -FreqOffset): the exactly reduced phase of the lane's first sample and of the distances 64 j (frame constants),
+    // sine / cosine in float -- the form of the demodulator above (a double sincospi per sample made this kernel 66 us per
+    // 4096 frames)
+    {
+      auto rotor = [&](int64_t i) {
+        double t = cfo * (double)i * inv;
+        t -= floor(t);
+        float sn, cs;
+        sincospif(2.0f * (float)t, &sn, &cs);
+        return mk<T>(cs, sn);
+      };
+      const cx<T> r0 = rotor((int64_t)N + lane), step = rotor(64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cx<T> cur = q == 0 ? r0 : r0 * rotor(512 * q);
+#pragma unroll
+        for (int j = 8 * q; j < 8 * q + 8; ++j) {
+          v[j] = v[j] * cur;
+          if (j + 1 < 8 * q + 8) cur = cur * step;
+        }
+      }
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < 4; ++j0) {
+      dft8<T, false>(v[j0], v[j0 + 4], v[j0 + 8], v[j0 + 12], v[j0 + 16], v[j0 + 20], v[j0 + 24], v[j0 + 28]);
+      if (j0 > 0) {
+#pragma unroll
+        for (int ka = 1; ka < 8; ++ka) v[j0 + 4 * ka] = v[j0 + 4 * ka] * t4w_w32(j0 * ka);
+      }
+    }
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka) dft4<T, false>(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3]);
+    int first = 0x7fffffff;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int ka = 0; ka < 8; ++ka) {
+        const int kj = ka + 8 * kb;
+        t1w[72 * ka] = kj == 0 ? v[kb] : v[kb + 4 * ka] * tw32_at(kj - 1);
+      }
+      wave_sync();
+      cx<T> u[8];
+      lds_read8<8, true>(u, t1r);
+      wave_sync();
+      dft8<T, false>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+#pragma unroll
+      for (int t = 1; t < 8; ++t) u[t] = u[t] * twbl_at(t - 1);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) t2w[t] = u[t];
+      wave_sync();
+      lds_read8<65, true>(u, t2r);
+      wave_sync();
+      dft8<T, false>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {                                   // bin (lane >> 3) + 8 kb + 32 (lane & 7) + 256 q
+        const bool above = sqrt((double)u[q].x * u[q].x + (double)u[q].y * u[q].y) > thr;
+        const int k = (lane >> 3) + 8 * kb + 32 * (lane & 7) + 256 * q;
+        if (above && k < first) first = k;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+    if (lane == 0) {
+      const int32_t r = first == 0x7fffffff ? -1 : first;
+      ifo_out[f] = r;
+      if (r < 0 && status[f] >= 0) status[f] = -1;
+    }
+  }
+}
+
+int t4_ifo_wave_launch(const void* rx, const void* tw, int64_t len, int t_guard, int64_t F, int td, const int64_t* tg,
+                       const double* fo, int32_t* ifo_out, int32_t* status) {
+  const unsigned grid = (unsigned)std::min<int64_t>((F + T4W_WPB - 1) / T4W_WPB, (int64_t)ctx().num_cu * 8);
+  hipLaunchKernelGGL(t4_ifo_wave_kernel, dim3(grid), dim3(64 * T4W_WPB), T4W_LDS, ctx().stream, (const cx<float>*)rx, (const cx<float>*)tw,
+                     len, t_guard, F, td, tg, fo, 0.77, ifo_out, status);
+  return check_launch("t4_ifo_wave_kernel");
+}
+
 bool t4_demod_wave_supported(int nfft, int n_keep, int np, bool f64) {
   return !f64 && nfft == T4W_N && n_keep <= 1024 && (n_keep & 1) == 0 && !getenv("OFDM_T4_NO_WAVE");   // even: 16-byte row alignment
 }
