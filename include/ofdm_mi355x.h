@@ -114,6 +114,9 @@ int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_
 /* One Noise() call per frame (power measured per frame, Philox stream = stream0 + frame). */
 int ofdm_Noise_frames(double snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
                       uint32_t stream0, void* y, int flags);
+/* The same with frame f at its own snr_db[f] (HOST array): the SNR sweep of T5/Main_model_Task_5.m:305-307 as a batch. */
+int ofdm_Noise_frames_snr(const double* snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
+                          uint32_t stream0, void* y, int flags);
 /* T5/add_STO.m:1-10 and T5/add_CFO.m:1-8. */
 int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags);
 int ofdm_add_CFO(const void* y, int64_t len, double cfo, int nfft, void* out, int flags);
@@ -275,6 +278,18 @@ int64_t ofdm_rx_plan_frame_bytes(const ofdm_rx_plan* plan);   /* packed bytes pe
 int ofdm_task5_part2_tile(ofdm_rx_plan* plan, const void* tx_noised, const int32_t* tap_delay, const double* tap_amp,
                           int n_ch_taps, int64_t n_frames, double snr_db, const uint8_t* ref_bits, double* nmse_out,
                           uint32_t* errors_out, int flags);
+/* One tile of the MSE(SNR) sweep of T5/Main_model_Task_5.m:303-346: the frames of the tile are its n_points SNR values.
+ * Per point i:  Noise(snr_db[i], Tx) (:307; Philox stream stream0 + i, key = seed) -> conv(Rx, h) truncated (:308-309) ->
+ * OFDM_demodulator (:311) -> LS_CE (:313) -> MMSE_CE with h = ifft(H_est_LS) and snr_db[i] (:314-315) -> MP_estimate and
+ * OMP_estimate on Y = RX(pilotCarriers, 1) ./ pilot column with dominant_taps = the plan's (:328-331; the plan's K = the
+ * dictionary's columns, :318-320) -> the four mean squared errors against fft(h) on carriers 1..N_carrier (:334-344).
+ *   tx[(nfft+t_guard)*n_symb]: the clean TX stream (DEVICE or HOST per flags); tap_delay[n_ch_taps] (0-based sample delays) /
+ *   tap_amp[n_ch_taps] (interleaved complex double): the channel, HOST; snr_db[n_points]: HOST;
+ *   mse_out[4][n_points] (double, where `flags` says): rows LS, MMSE, MP, OMP.
+ * The plan may have no data carriers (comb = 1, the script as committed: pilots on every carrier).  Everything stays on the
+ * device: the 61-point sweep of the script is one call.  At most 65535 points and 64 channel taps per call. */
+int ofdm_task5_mse_tile(ofdm_rx_plan* plan, const void* tx, const int32_t* tap_delay, const double* tap_amp, int n_ch_taps,
+                        const double* snr_db, int64_t n_points, uint64_t seed, uint32_t stream0, double* mse_out, int flags);
 /* Measurement aid: with timing enabled every ofdm_rx_chain_task5 call brackets its launches with HIP
  * events on the launch stream; ms3 = {symbol-1 kernel, OMP kernel, symbols kernel} of the last call
  * (comb pilot layouts run the first two as one launch and report {symbol-1 + OMP kernel, 0, symbols

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ofdm_Noise": [_d, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _pd, _i],
     "ofdm_channel_conv_frames": [_vp, _i64, _i64, _vp, _i, _vp, _i],
     "ofdm_Noise_frames": [_d, _vp, _i64, _i64, C.c_uint64, C.c_uint32, _vp, _i],
+    "ofdm_Noise_frames_snr": [_vp, _vp, _i64, _i64, C.c_uint64, C.c_uint32, _vp, _i],
     "ofdm_add_STO": [_vp, _i64, _i64, _vp, _i],
     "ofdm_add_CFO": [_vp, _i64, _d, _i, _vp, _i],
     "ofdm_add_STO_CFO_frames": [_vp, _i64, _i64, _vp, _vp, _i, _vp, _i],
@@ -79,6 +80,7 @@ SIGNATURES = {
     "ofdm_rx_plan_last_task4_ms": [_vp, C.POINTER(C.c_float)],
     "ofdm_rx_chain_task5": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i],
     "ofdm_task5_part2_tile": [_vp, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp, _i],
+    "ofdm_task5_mse_tile": [_vp, _vp, _vp, _vp, _i, _vp, _i64, C.c_uint64, C.c_uint32, _vp, _i],
 }
 _RESTYPES = {"ofdm_last_error_string": C.c_char_p, "ofdm_rx_plan_frame_bytes": C.c_int64}
 

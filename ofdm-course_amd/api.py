@@ -35,7 +35,7 @@ __all__ = [
     "OFDM_modulator", "OFDM_demodulator", "get_MP_channel_resp", "apply_channel", "Noise", "add_STO",
     "add_CFO", "add_STO_CFO_frames", "apply_channel_frames", "Noise_frames", "AutoCorrFunction", "remove_IFO", "fine_sync", "estimate_channel", "equalize_signal",
     "interpolate", "LS_CE", "MMSE_CE", "sensing_matrix", "MP_estimate", "OMP_estimate", "BER_func",
-    "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "task5_part2_tile", "DEFAULT_REGISTER",
+    "MER_func", "calculatePAPR", "calculate_window_PAPR", "calculateCCDF", "RxPlan", "rx_chain_task5", "rx_chain_task4", "task5_part2_tile", "task5_mse_tile", "DEFAULT_REGISTER",
 ]
 
 DEFAULT_REGISTER = (1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0)   # T5/Main_model_Task_5.m:55
@@ -871,3 +871,22 @@ def task5_part2_tile(plan: RxPlan, tx_noised, taps_list, SNR_dB, ref_bits_packed
                                            C.c_void_p(ampv.ctypes.data), T, n, float(SNR_dB), pref, pnm, per, call.flags),
             "task5_part2_tile")
     return dict(nmse=nm.T, errors=er.T)
+
+
+def task5_mse_tile(plan: RxPlan, Tx, channel_taps, SNRs, seed=0, stream0=0):
+    """One tile of the MSE(SNR) sweep of T5/Main_model_Task_5.m:303-346 (ofdm_task5_mse_tile): for every SNR of `SNRs`
+    Noise(SNR, Tx) (Philox stream stream0 + i) -> conv(h) truncated -> OFDM_demodulator -> LS_CE, MMSE_CE(h = ifft(H_LS), SNR),
+    MP_estimate, OMP_estimate -> mean squared error against fft(h) on 1..N_carrier.  Tx: the clean TX stream of one frame
+    (numpy -> host flavour, torch.cuda -> device flavour); channel_taps: [(delay, amplitude)] rows like the script's.
+    Returns MSEs [4, n] float64, rows LS, MMSE, MP, OMP."""
+    call = _Call(Tx, f64=plan.f64)
+    t = np.asarray(channel_taps)
+    delay = np.ascontiguousarray(np.real(t[:, 0]).astype(np.int32))
+    amp = np.ascontiguousarray(t[:, 1].astype(np.complex128)).view(np.float64)
+    snr = np.ascontiguousarray(np.asarray(SNRs, dtype=np.float64).ravel())
+    n = snr.size
+    ms, pms = call._out((n, 4), np.float64, torch.float64 if call.dev else None)      # memory [4][n]
+    L.check(call.lib.ofdm_task5_mse_tile(plan.handle, call.cin(Tx), C.c_void_p(delay.ctypes.data), C.c_void_p(amp.ctypes.data),
+                                         delay.size, C.c_void_p(snr.ctypes.data), n, int(seed), int(stream0), pms, call.flags),
+            "task5_mse_tile")
+    return ms.T

@@ -432,7 +432,9 @@ int ofdm_rx_plan_create(ofdm_rx_plan** plan_out, int nfft, int t_guard, int n_sy
   OFDM_ARG(plan_out, "rx_plan_create: null output");
   OFDM_ARG(fft_size_supported(nfft), "rx_plan_create: unsupported Nfft %d", nfft);
   OFDM_ARG(t_guard >= 0 && n_symb >= 1 && n_carrier >= 1 && n_carrier <= nfft, "rx_plan_create: bad frame geometry");
-  OFDM_ARG(n_pilots >= 1 && n_pilots < 32768 && n_data >= 1 && n_data < 32768, "rx_plan_create: bad carrier counts");
+  // n_data = 0: a pilots-only plan (T5/Main_model_Task_5.m as committed, comb = 1) -- for ofdm_task5_mse_tile; the decoding
+  // entries refuse it
+  OFDM_ARG(n_pilots >= 1 && n_pilots < 32768 && n_data >= 0 && n_data < 32768, "rx_plan_create: bad carrier counts");
   OFDM_ARG(k_atoms >= 1 && k_atoms <= nfft && dominant_taps >= 1 && dominant_taps <= CH_MAXT && dominant_taps <= k_atoms,
            "rx_plan_create: needs 1 <= taps <= %d, taps <= K <= Nfft", CH_MAXT);
   OFDM_ARG(dominant_taps <= nfft / 8, "rx_plan_create: taps exceed the group size");
@@ -630,6 +632,7 @@ int ofdm_rx_chain_task5(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, uint
   OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "rx_chain_task5: precision flag differs from the plan's");
   OFDM_ARG(!errors_out || ref_bits, "rx_chain_task5: errors_out needs ref_bits");
+  OFDM_ARG(pl->nd >= 1, "rx_chain_task5: the plan has no data carriers");
   if (n_frames == 0) return OFDM_OK;
   const size_t cs = csize(flags);
   const size_t frame_samples = (size_t)(pl->nfft + pl->t_guard) * pl->n_symb;

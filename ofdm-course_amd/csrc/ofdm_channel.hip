@@ -70,15 +70,17 @@ __global__ void power_partial_kernel(const cx<T>* __restrict__ xall, int64_t len
 
 // out[0] = sqrt(NoisePower/2) (per-component sigma), out[1] = sqrt(NoisePower) (N_var of Noise.m:11).
 // One wavefront per frame (a single thread walking 2048 partial sums cost more than the noise pass it feeds).
+// snr_lin_v (optional): the frame's own 10^(SNR/10) -- a sweep whose frames are its SNR points (T5/Main_model_Task_5.m:305-307)
 __global__ __launch_bounds__(64) void noise_sigma_kernel(const double* __restrict__ partial, int n_part, int64_t len, double snr_lin,
-                                                         double* __restrict__ out, int64_t n_frames) {
+                                                         double* __restrict__ out, int64_t n_frames,
+                                                         const double* __restrict__ snr_lin_v = nullptr) {
   const int64_t f = blockIdx.x;
   double s = 0;
   for (int i = threadIdx.x; i < n_part; i += 64) s += partial[f * n_part + i];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (threadIdx.x == 0) {
     const double p = s / (double)len;             // Noise.m:3
-    const double np = p / snr_lin;                // :5
+    const double np = p / (snr_lin_v ? snr_lin_v[f] : snr_lin);   // :5
     out[2 * f] = sqrt(np / 2.0);
     out[2 * f + 1] = sqrt(np);
   }
@@ -310,7 +312,7 @@ int ofdm_channel_conv_frames(const void* x, int64_t frame_len, int64_t n_frames,
 }
 
 static int noise_common(double snr_db, const void* x, int64_t len, int64_t n_frames, uint64_t seed, uint32_t stream,
-                        void* y, double* n_var_out, int flags) {
+                        void* y, double* n_var_out, int flags, const double* snr_db_v = nullptr) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(len >= 0 && n_frames >= 0 && n_frames < 65536 * 1024, "Noise: bad sizes");
   if (len == 0 || n_frames == 0) { if (n_var_out) *n_var_out = NAN; return OFDM_OK; }
@@ -328,12 +330,19 @@ static int noise_common(double snr_db, const void* x, int64_t len, int64_t n_fra
   if (want) OFDM_TRY(st.fetch(sig_host, sizeof(sig_host), &dsig));
   else OFDM_TRY(st.scratch(sizeof(double) * 2 * (size_t)n_frames, &dsig));
   const double snr_lin = std::pow(10.0, snr_db / 10.0);
+  const void* dsnr = nullptr;
+  std::vector<double> lin;
+  if (snr_db_v) {
+    lin.resize((size_t)n_frames);
+    for (int64_t f = 0; f < n_frames; ++f) lin[f] = std::pow(10.0, snr_db_v[f] / 10.0);
+    OFDM_TRY(st.upload(lin.data(), sizeof(double) * lin.size(), &dsnr));
+  }
   const dim3 pgrid(bpf, (unsigned)n_frames);
   if (f64) hipLaunchKernelGGL(power_partial_kernel<double>, pgrid, dim3(256), 0, ctx().stream, (const c64*)dx, len, (double*)dpart);
   else hipLaunchKernelGGL(power_partial_kernel<float>, pgrid, dim3(256), 0, ctx().stream, (const c32*)dx, len, (double*)dpart);
   OFDM_TRY(check_launch("power_partial_kernel"));
   hipLaunchKernelGGL(noise_sigma_kernel, dim3((unsigned)n_frames), dim3(64), 0, ctx().stream, (const double*)dpart,
-                     (int)bpf, len, snr_lin, (double*)dsig, n_frames);
+                     (int)bpf, len, snr_lin, (double*)dsig, n_frames, (const double*)dsnr);
   OFDM_TRY(check_launch("noise_sigma_kernel"));
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   unsigned abx = (unsigned)std::min<int64_t>((len + 255) / 256, n_frames > 1 ? 64 : (int64_t)ctx().num_cu * 8);
@@ -354,6 +363,12 @@ int ofdm_Noise(double snr_db, const void* x, int64_t len, uint64_t seed, uint32_
 int ofdm_Noise_frames(double snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
                       uint32_t stream0, void* y, int flags) {
   return noise_common(snr_db, x, frame_len, n_frames, seed, stream0, y, nullptr, flags);
+}
+
+int ofdm_Noise_frames_snr(const double* snr_db, const void* x, int64_t frame_len, int64_t n_frames, uint64_t seed,
+                          uint32_t stream0, void* y, int flags) {
+  OFDM_ARG(snr_db, "Noise_frames_snr: null SNR array");
+  return noise_common(0.0, x, frame_len, n_frames, seed, stream0, y, nullptr, flags, snr_db);
 }
 
 int ofdm_add_STO(const void* y, int64_t len, int64_t n_sto, void* out, int flags) {

@@ -107,11 +107,15 @@ __device__ __forceinline__ double p2_wave_sum(double v) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void mmse_wave_kernel(const cx<T>* __restrict__ ypil, const double* __restrict__ cvals,
-                                                        double inv_snr, int np, cx<T>* __restrict__ vout, int64_t n_frames) {
+                                                        double inv_snr, int np, cx<T>* __restrict__ vout, int64_t n_frames,
+                                                        const double* __restrict__ inv_snr_v = nullptr) {
+  // blockDim.x / 64 realisations per workgroup (4 while their state fits the LDS, fewer for many pilots);
+  // inv_snr_v (optional): every realisation at its own SNR (the SNR sweep of Main_model_Task_5.m:305-315)
   extern __shared__ __attribute__((aligned(16))) unsigned char p2_smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t f = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (f >= n_frames) return;                                       // no workgroup barrier below
+  if (inv_snr_v) inv_snr = inv_snr_v[f];
   c64* tcol = (c64*)p2_smem + (size_t)wave * 4 * np;               // [np] each: tcol, fv, bv, xv
   c64 *fv = tcol + np, *bv = fv + np, *xv = bv + np;
   const cx<T>* y = ypil + f * np;
@@ -415,6 +419,187 @@ static int part2_tile_run(ofdm_rx_plan* pl, const void* dtx, const int32_t* ddel
   return check_launch("p2_nmse_kernel");
 }
 
+
+// ---- MMSE_CE.m:18-25 with h = ifft(H_est_LS) (Main_model_Task_5.m:314-315): the N_carrier-point inverse DFT of the LS estimate
+// (any N_carrier: direct sums over a table of the N_carrier-th roots of unity, exact index arithmetic), then
+// hh = h h', r = sum(|h|^2 k) / hh, r2 = sum(|h|^2 k^2) / hh, tau_rms = sqrt(r2 - r^2); cvals[f] = 2 pi tau_rms df Nps.
+template <typename T>
+__global__ __launch_bounds__(256) void mse_tau_kernel(const cx<T>* __restrict__ hls, int nc, double nps, double* __restrict__ cvals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char p2_smem[];
+  c64* const root = (c64*)p2_smem;                                  // exp(+2 pi i j / nc)
+  c64* const hl = root + nc;                                        // the frame's H_est_LS in double
+  __shared__ double red[3][4];
+  const int64_t f = blockIdx.x;
+  for (int j = threadIdx.x; j < nc; j += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)j / (double)nc, &sn, &cs);
+    root[j] = c64{cs, sn};
+    const cx<T> v = hls[f * nc + j];
+    hl[j] = c64{(double)v.x, (double)v.y};
+  }
+  __syncthreads();
+  double hh = 0, s1 = 0, s2 = 0;
+  for (int k = threadIdx.x; k < nc; k += 256) {
+    double ar = 0, ai = 0;
+    int e = 0;                                                      // (k m) mod nc
+    for (int m = 0; m < nc; ++m) {
+      const c64 w = root[e], x = hl[m];
+      ar += x.x * w.x - x.y * w.y;
+      ai += x.x * w.y + x.y * w.x;
+      e += k;
+      if (e >= nc) e -= nc;
+    }
+    ar /= (double)nc; ai /= (double)nc;                             // ifft scaling
+    const double p = ar * ar + ai * ai;
+    hh += p; s1 += p * (double)k; s2 += p * (double)k * (double)k;
+  }
+  double v[3] = {hh, s1, s2};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, 64);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double H = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double r = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / H, r2 = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) / H;
+    cvals[f] = 2.0 * M_PI * sqrt(r2 - r * r) * (1.0 / (double)nc) * nps;      // :23-26, df = 1 / N_carrier
+  }
+}
+
+// ---- H(1..N_carrier) = fft(h_est) from the picked taps of MP / OMP (MP_estimate.m:27-33, OMP_estimate.m:25-36): a later pick of
+// the same atom overwrites the earlier one (est(index(i)) = x(i)).
+template <typename T>
+__global__ __launch_bounds__(256) void mse_taps_to_h_kernel(const int32_t* __restrict__ tap_idx, const c64* __restrict__ tap_x, int taps,
+                                                            int nfft, int nc, cx<T>* __restrict__ hout) {
+  const int64_t f = blockIdx.x;
+  for (int k = threadIdx.x; k < nc; k += 256) {
+    double hr = 0, hi = 0;
+    for (int q = 0; q < taps; ++q) {
+      const int idx = tap_idx[f * taps + q];
+      if (idx < 0) continue;
+      bool later = false;
+      for (int q2 = q + 1; q2 < taps; ++q2) later = later || tap_idx[f * taps + q2] == idx;
+      if (later) continue;
+      const int e = (int)(((int64_t)idx * k) % nfft);
+      double sn, cs;
+      sincospi(2.0 * (double)e / (double)nfft, &sn, &cs);
+      const c64 a = tap_x[f * taps + q];
+      hr += a.x * cs + a.y * sn;
+      hi += a.y * cs - a.x * sn;
+    }
+    hout[f * nc + k] = mk<T>((T)hr, (T)hi);
+  }
+}
+
+template <typename T>
+static int mse_tile_run(ofdm_rx_plan* pl, const void* dtx, const void* h_dense, int h_len, const int32_t* ddelay, const c64* damp,
+                        int n_ch, const double* snr_db_host, const double* dinv_snr, int64_t F, uint64_t seed, uint32_t stream0,
+                        double* dmse, int flags) {
+  const int N = pl->nfft, Tg = pl->t_guard, S = pl->n_symb, np = pl->np, nc = pl->n_carrier, taps = pl->taps;
+  const int64_t len = (int64_t)(N + Tg) * S;
+  const bool f64 = std::is_same<T, double>::value;
+  hipStream_t st = ctx().stream;
+  const int devflags = (flags & ~OFDM_DEVICE) | OFDM_DEVICE;
+  size_t need = 0;
+  auto reserve = [&](size_t bytes) { const size_t o = need; need += (bytes + 255) & ~size_t(255); return o; };
+  const size_t o_a = reserve(sizeof(cx<T>) * (size_t)len * F), o_b = reserve(sizeof(cx<T>) * (size_t)len * F);
+  const size_t o_x = reserve(sizeof(cx<T>) * (size_t)nc * S * F), o_v = reserve(sizeof(cx<T>) * (size_t)np * F);
+  const size_t o_c = reserve(sizeof(double) * (size_t)F);
+  size_t o_h[4];
+  for (int e = 0; e < 4; ++e) o_h[e] = reserve(sizeof(cx<T>) * (size_t)nc * F);
+  if (pl->ws_t4_bytes < need) {                                     // the Task-4 arena doubles as this entry's
+    OFDM_HIP(hipStreamSynchronize(st));
+    if (pl->ws_t4) { (void)hipFree(pl->ws_t4); pl->ws_t4 = nullptr; pl->ws_t4_bytes = 0; }
+    OFDM_HIP(hipMalloc(&pl->ws_t4, need));
+    pl->ws_t4_bytes = need;
+  }
+  unsigned char* arena = (unsigned char*)pl->ws_t4;
+  cx<T>* da = (cx<T>*)(arena + o_a);
+  cx<T>* db = (cx<T>*)(arena + o_b);
+  cx<T>* dxk = (cx<T>*)(arena + o_x);
+  cx<T>* dv = (cx<T>*)(arena + o_v);
+  double* dcv = (double*)(arena + o_c);
+  cx<T>* dh[4];
+  for (int e = 0; e < 4; ++e) dh[e] = (cx<T>*)(arena + o_h[e]);
+  if (!pl->d_p2_sop) {
+    std::vector<double> W;
+    OFDM_TRY(build_interpolate_operator(pl->pilot_loc.data(), np, nc, 's', W));
+    OFDM_HIP(hipMalloc(&pl->d_p2_sop, sizeof(double) * W.size()));
+    OFDM_HIP(hipMemcpy(pl->d_p2_sop, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice));
+  }
+  FastPlanView pv;
+  make_plan_view(pl, pv);
+  pv.ev = nullptr;
+  pv.d_wt = nullptr;
+  FastParams<T> P;
+  const void* tw = nullptr;
+  OFDM_TRY(get_twiddles(N, f64, &tw));
+  OFDM_TRY(fast_params_prepare<T>(pv, tw, F, P));
+  // Tx for every point -> Noise at the point's SNR (:307) -> conv truncated (:308-309) -> demodulator (:311) -> Y (:328)
+  const int words = (int)(len * (int64_t)(sizeof(cx<T>) / 4));
+  OFDM_ARG((int64_t)words * F < ((int64_t)1 << 40), "task5_mse_tile: tile too large");
+  hipLaunchKernelGGL(p2_replicate_kernel<T>, dim3(cdiv_u((int64_t)F * words, 256)), dim3(256), 0, st, (const uint32_t*)dtx, (uint32_t*)da,
+                     words, F);
+  OFDM_TRY(check_launch("p2_replicate_kernel"));
+  OFDM_TRY(ofdm_Noise_frames_snr(snr_db_host, da, len, F, seed, stream0, da, devflags));
+  OFDM_TRY(ofdm_channel_conv_frames(da, len, F, h_dense, h_len, db, devflags));
+  OFDM_TRY(demod_keep_device(db, dxk, N, F * S, Tg, nc, f64));
+  hipLaunchKernelGGL(p2_pilot_ls_kernel<T>, dim3(cdiv_u(F * np, 256)), dim3(256), 0, st, (const cx<T>*)dxk, (const int32_t*)pl->d_pc0,
+                     (const cx<T>*)pl->d_pilots, P.ypil, np, S, nc, F);
+  // LS_CE (:313): H = Sop * Y
+  const dim3 og(cdiv_u(nc, 128), cdiv_u(F, P2_FT));
+  hipLaunchKernelGGL(p2_apply_operator_kernel<T>, og, dim3(128), sizeof(cx<T>) * np * P2_FT, st, (const double*)pl->d_p2_sop,
+                     (const cx<T>*)P.ypil, dh[0], nc, np, F);
+  // MMSE_CE (:314-315): tau_rms of ifft(H_est_LS), then v = rf2 (rf2 + I/snr_i)^-1 Y, H = Sop * v
+  {
+    const size_t tdyn = sizeof(c64) * 2 * (size_t)nc;
+    OFDM_ARG(tdyn <= 150 * 1024, "task5_mse_tile: N_carrier beyond 4800");
+    OFDM_HIP(hipFuncSetAttribute((const void*)mse_tau_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tdyn));
+    const double nps = (double)pl->pilot_loc[1] - (double)pl->pilot_loc[0];                    // MMSE_CE.m:15
+    hipLaunchKernelGGL(mse_tau_kernel<T>, dim3((unsigned)F), dim3(256), tdyn, st, (const cx<T>*)dh[0], nc, nps, dcv);
+    int wpw = 4;
+    while (wpw > 1 && sizeof(c64) * 4 * (size_t)np * wpw > 150 * 1024) wpw >>= 1;
+    const size_t dyn = sizeof(c64) * 4 * (size_t)np * wpw;
+    OFDM_ARG(dyn <= 150 * 1024, "task5_mse_tile: MMSE stage supports at most 2343 pilots");
+    OFDM_HIP(hipFuncSetAttribute((const void*)mmse_wave_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(mmse_wave_kernel<T>, dim3(cdiv_u(F, wpw)), dim3(64 * wpw), dyn, st, (const cx<T>*)P.ypil, (const double*)dcv, 0.0, np,
+                       dv, F, dinv_snr);
+    hipLaunchKernelGGL(p2_apply_operator_kernel<T>, og, dim3(128), sizeof(cx<T>) * np * P2_FT, st, (const double*)pl->d_p2_sop,
+                       (const cx<T>*)dv, dh[1], nc, np, F);
+  }
+  OFDM_TRY(check_launch("LS / MMSE stage"));
+  // MP_estimate (:330)
+  {
+    OFDM_ARG(pl->k_atoms >= np, "MP_estimate: the loop bound is Np columns (MP_estimate.m:10) but the dictionary has fewer");
+    const int kc = np;
+    const MpLayout lay = mp_layout<T>(np, kc, taps);
+    OFDM_ARG(lay.total <= 150 * 1024, "task5_mse_tile: MP stage needs %u bytes of LDS", lay.total);
+    const unsigned grid = cdiv_u(F, 4 * lay.fpw);
+    const bool mfma = !f64 && (kc % 16 == 0) && (np % 4 == 0) && !getenv("OFDM_MP_NO_MFMA");
+    if (mfma) {
+      if constexpr (!f64) {
+        OFDM_HIP(hipFuncSetAttribute((const void*)mp_batch_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+        hipLaunchKernelGGL((mp_batch_kernel<float, true>), dim3(grid), dim3(256), lay.total, st, P, lay, kc, F);
+      }
+    } else {
+      OFDM_HIP(hipFuncSetAttribute((const void*)mp_batch_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+      hipLaunchKernelGGL((mp_batch_kernel<T, false>), dim3(grid), dim3(256), lay.total, st, P, lay, kc, F);
+    }
+    hipLaunchKernelGGL(mse_taps_to_h_kernel<T>, dim3((unsigned)F), dim3(256), 0, st, (const int32_t*)P.tap_idx, (const c64*)P.tap_x, taps, N, nc,
+                       dh[2]);
+    OFDM_TRY(check_launch("MP stage"));
+  }
+  // OMP_estimate (:331)
+  OFDM_TRY(omp_batch_run<T>(P, F));
+  hipLaunchKernelGGL(mse_taps_to_h_kernel<T>, dim3((unsigned)F), dim3(256), 0, st, (const int32_t*)P.tap_idx, (const c64*)P.tap_x, taps, N, nc,
+                     dh[3]);
+  // the four errors against fft(h)(1..N_carrier) (:334-344)
+  hipLaunchKernelGGL(p2_nmse_kernel<T>, dim3((unsigned)F), dim3(256), 0, st, ddelay, damp, n_ch, N, nc, (const cx<T>*)dh[0],
+                     (const cx<T>*)dh[1], (const cx<T>*)dh[2], (const cx<T>*)dh[3], dmse, F);
+  return check_launch("p2_nmse_kernel");
+}
+
 }  // namespace ofdm
 
 using namespace ofdm;
@@ -425,6 +610,7 @@ extern "C" int ofdm_task5_part2_tile(ofdm_rx_plan* pl, const void* tx_noised, co
   OFDM_TRY(ensure_init());
   OFDM_ARG(!pl || !(pl->descr & DESCR_ON), "task5_part2_tile: the study runs unscrambled (Task5_part2.m:104-114,:285-299 are commented out); clear the plan's DeScrambler");
   OFDM_ARG(pl && tx_noised && tap_delay && tap_amp && ref_bits && nmse_out && errors_out, "task5_part2_tile: null argument");
+  OFDM_ARG(pl->nd >= 1, "task5_part2_tile: the plan has no data carriers");
   OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "task5_part2_tile: precision flag differs from the plan's");
   OFDM_ARG(pl->pilots_in_band && pl->np >= 2, "task5_part2_tile: needs at least two pilots, all inside 1..N_carrier");
@@ -465,5 +651,63 @@ extern "C" int ofdm_task5_part2_tile(ofdm_rx_plan* pl, const void* tx_noised, co
                                                 inv_snr, dref, (double*)dnm, (uint32_t*)der));
   else OFDM_TRY(part2_tile_run<float>(pl, dtx, (const int32_t*)ddel, (const c64*)damp, n_ch_taps, n_frames, (const double*)dcv, inv_snr,
                                       dref, (double*)dnm, (uint32_t*)der));
+  return st.finish();
+}
+
+extern "C" int ofdm_task5_mse_tile(ofdm_rx_plan* pl, const void* tx, const int32_t* tap_delay, const double* tap_amp, int n_ch_taps,
+                                   const double* snr_db, int64_t n_points, uint64_t seed, uint32_t stream0, double* mse_out,
+                                   int flags) {
+  OFDM_TRY(ensure_init());
+  OFDM_ARG(pl && tx && tap_delay && tap_amp && snr_db && mse_out, "task5_mse_tile: null argument");
+  OFDM_PLAN_DEVICE(pl);
+  OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "task5_mse_tile: precision flag differs from the plan's");
+  OFDM_ARG(pl->pilots_in_band && pl->np >= 2, "task5_mse_tile: needs at least two pilots, all inside 1..N_carrier");
+  OFDM_ARG(n_ch_taps >= 1 && n_ch_taps <= 64 && n_points >= 0 && n_points <= 65535, "task5_mse_tile: 1..64 channel taps, at most 65535 points");
+  OFDM_ARG((int64_t)stream0 + n_points < ((int64_t)1 << 32), "task5_mse_tile: stream index outside 32 bits");
+  if (n_points == 0) return OFDM_OK;
+  const size_t cs = csize(flags);
+  const int64_t len = (int64_t)(pl->nfft + pl->t_guard) * pl->n_symb;
+  // dense impulse response for conv (get_MP_channel_resp.m: amplitudes at their delays), the channel per point for the error
+  // kernel, 1 / snr per point (MMSE_CE.m:13)
+  int h_len = 0;
+  for (int t = 0; t < n_ch_taps; ++t) {
+    OFDM_ARG(tap_delay[t] >= 0 && tap_delay[t] < pl->nfft, "task5_mse_tile: tap delay outside 0..Nfft-1");
+    h_len = std::max(h_len, tap_delay[t] + 1);
+  }
+  std::vector<c64> h64((size_t)h_len, c64{0, 0});
+  for (int t = 0; t < n_ch_taps; ++t) h64[tap_delay[t]] = c64{tap_amp[2 * t], tap_amp[2 * t + 1]};   // a later tap at the same delay wins
+  std::vector<c32> h32;
+  const void* h_dense = h64.data();
+  if (!pl->f64) {
+    h32.resize(h64.size());
+    for (size_t i = 0; i < h64.size(); ++i) h32[i] = c32{(float)h64[i].x, (float)h64[i].y};
+    h_dense = h32.data();
+  }
+  std::vector<int32_t> del((size_t)n_points * n_ch_taps);
+  std::vector<double> amp(2 * (size_t)n_points * n_ch_taps), inv_snr((size_t)n_points);
+  for (int64_t f = 0; f < n_points; ++f) {
+    for (int t = 0; t < n_ch_taps; ++t) {
+      // the dense vector is what the script convolves with: the error is measured against ITS transform
+      del[f * n_ch_taps + t] = tap_delay[t];
+      const c64 a = h64[tap_delay[t]];
+      bool dup = false;
+      for (int t2 = t + 1; t2 < n_ch_taps; ++t2) dup = dup || tap_delay[t2] == tap_delay[t];
+      amp[2 * (f * n_ch_taps + t)] = dup ? 0.0 : a.x;
+      amp[2 * (f * n_ch_taps + t) + 1] = dup ? 0.0 : a.y;
+    }
+    inv_snr[f] = 1.0 / pow(10.0, snr_db[f] * 0.1);
+  }
+  Stage st(flags);
+  const void *dtx, *ddel, *damp, *dinv;
+  void* dms;
+  OFDM_TRY(st.in(tx, cs * (size_t)len, &dtx));
+  OFDM_TRY(st.upload(del.data(), sizeof(int32_t) * del.size(), &ddel));
+  OFDM_TRY(st.upload(amp.data(), sizeof(double) * amp.size(), &damp));
+  OFDM_TRY(st.upload(inv_snr.data(), sizeof(double) * inv_snr.size(), &dinv));
+  OFDM_TRY(st.out(mse_out, sizeof(double) * 4 * (size_t)n_points, &dms));
+  if (pl->f64) OFDM_TRY(mse_tile_run<double>(pl, dtx, h_dense, h_len, (const int32_t*)ddel, (const c64*)damp, n_ch_taps, snr_db,
+                                              (const double*)dinv, n_points, seed, stream0, (double*)dms, flags));
+  else OFDM_TRY(mse_tile_run<float>(pl, dtx, h_dense, h_len, (const int32_t*)ddel, (const c64*)damp, n_ch_taps, snr_db, (const double*)dinv,
+                                    n_points, seed, stream0, (double*)dms, flags));
   return st.finish();
 }

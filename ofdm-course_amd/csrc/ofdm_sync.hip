@@ -1153,6 +1153,7 @@ int ofdm_rx_chain_task4(ofdm_rx_plan* pl, const void* rx, int64_t n_frames, int 
                         double* freq_offset_out, int32_t* ifo_out, int32_t* status_out, void* h_out, int flags) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(pl && rx && n_frames >= 0, "rx_chain_task4: bad arguments");
+  OFDM_ARG(pl->nd >= 1, "rx_chain_task4: the plan has no data carriers");
   OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "rx_chain_task4: precision flag differs from the plan's");
   OFDM_ARG(pl->pilots_in_band, "rx_chain_task4: pilots outside 1..N_carrier are not supported");

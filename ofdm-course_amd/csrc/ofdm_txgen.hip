@@ -152,6 +152,7 @@ extern "C" int ofdm_tx_frames_ex(ofdm_rx_plan* pl, const void* h, int h_len, dou
                                  uint8_t* bits_out, uint8_t* sc_ref_bits_out, int64_t* sto_out, double* cfo_out, int flags) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(pl && n_frames >= 0 && rx_out, "tx_frames: bad arguments");
+  OFDM_ARG(pl->nd >= 1, "tx_frames: the plan has no data carriers");
   OFDM_PLAN_DEVICE(pl);
   OFDM_ARG((is_f64(flags) ? 1 : 0) == pl->f64, "tx_frames: precision flag differs from the plan's");
   OFDM_ARG(pl->pilots_in_band, "tx_frames: pilots outside 1..N_carrier are not supported");

@@ -28,8 +28,15 @@ def _estimates(lib, Xr, pilotValues, pilotCarriers, Nfft, N_carrier, amp_col, S,
 
 
 def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_SpF=7, comb=1,
-        Constellation="16QAM", SNR_dB=20, noise_desync=1, mp_desync=1, SNRs=None, channel_taps=None, seed=1):
-    """T5/Main_model_Task_5.m.  comb = 1 (as committed, :13) sends pilots only; comb > 1 also decodes a payload."""
+        Constellation="16QAM", SNR_dB=20, noise_desync=1, mp_desync=1, SNRs=None, channel_taps=None, seed=1,
+        batched=None, precision="fp64", rank=0, world=1):
+    """T5/Main_model_Task_5.m.  comb = 1 (as committed, :13) sends pilots only; comb > 1 also decodes a payload.
+
+    batched: run the MSE(SNR) sweep of :303-346 as device-resident tiles (`lib.task5_mse_tile`: noise, channel, demodulator
+    and the four estimators of all SNR points in one call) instead of point by point; default = whenever `lib` has that
+    entry (the HIP library does, the oracle adapter of the tests does not).  precision: of the batched tile.
+    rank / world: the SNR points are independent; every rank takes a contiguous block of them (one tile call) and fills
+    its own columns of `MSEs` (the others stay 0: one SUM all-reduce assembles the table)."""
     lib = lib or c.default_lib()
     T_Guard = Nfft // 8
     N_symb = Amount_OFDM_Frames * Amount_ODFM_SpF
@@ -78,13 +85,28 @@ def run(lib=None, Nfft=4096, N_carrier=1024, Amount_OFDM_Frames=2, Amount_ODFM_S
 
     SNRs = np.arange(0, 30.5, 0.5) if SNRs is None else np.asarray(SNRs, dtype=float)           # :303
     MSEs = np.zeros((4, len(SNRs)))                                                             # :304 LS, MMSE, MP, OMP
-    for i, snr in enumerate(SNRs):                                                              # :305
-        Rx_i, _ = lib.Noise(float(snr), Tx, seed=seed, stream=1 + i)                            # :307
-        Rx_i = c.conv_truncate(lib, Rx_i, H_tau)                                                # :308-309
-        Xi = lib.OFDM_demodulator(np.asarray(Rx_i).reshape((Nfft + T_Guard, N_symb), order="F"), T_Guard)   # :310-311
-        _, mse, _ = _estimates(lib, Xi, pilotValues, pilotCarriers, Nfft, N_carrier, amp_pilots, S,
-                               taps.shape[0], float(snr), H_freq)
-        MSEs[:, i] = [mse["LS"], mse["MMSE"], mse["MP"], mse["OMP"]]                            # :341-344
+    n_pts = len(SNRs)
+    mine = list(range(rank * n_pts // world, (rank + 1) * n_pts // world))      # a contiguous block per rank: one tile call
+    use_tile = (batched if batched is not None else hasattr(lib, "task5_mse_tile")) and len(mine) > 0
+    if use_tile:
+        # :305-345 for all of this rank's SNR points in one call; point i draws its noise from stream 1 + i as below
+        plan = lib.RxPlan(Nfft, T_Guard, N_symb, N_carrier, pilotCarriers, dataCarriers, pilotValues[:, 0], K, taps.shape[0],
+                          Constellation, precision=precision)
+        cdt = np.complex128 if precision == "fp64" else np.complex64
+        for i0 in range(0, len(mine), 4096):
+            r = mine[i0:i0 + 4096]
+            MSEs[:, r] = np.asarray(lib.task5_mse_tile(plan, np.asarray(Tx).astype(cdt), taps, SNRs[r], seed=seed,
+                                                       stream0=1 + r[0]))
+        plan.close()
+    else:
+        for i in mine:                                                                          # :305
+            snr = SNRs[i]
+            Rx_i, _ = lib.Noise(float(snr), Tx, seed=seed, stream=1 + i)                        # :307
+            Rx_i = c.conv_truncate(lib, Rx_i, H_tau)                                            # :308-309
+            Xi = lib.OFDM_demodulator(np.asarray(Rx_i).reshape((Nfft + T_Guard, N_symb), order="F"), T_Guard)   # :310-311
+            _, mse, _ = _estimates(lib, Xi, pilotValues, pilotCarriers, Nfft, N_carrier, amp_pilots, S,
+                                   taps.shape[0], float(snr), H_freq)
+            MSEs[:, i] = [mse["LS"], mse["MMSE"], mse["MP"], mse["OMP"]]                        # :341-344
     res["sweep"] = {"SNRs": SNRs, "estimators": ["LS", "MMSE", "MP", "OMP"], "MSEs": MSEs}
     return res
 

@@ -91,6 +91,25 @@ def test_task5_estimator_tables(drivers, ofdm, olib):
     np.testing.assert_allclose(g["_H_est"], o["_H_est"], rtol=1e-10, atol=1e-10)   # spline extrapolates to ~1e8 beyond N_carrier
 
 
+@pytest.mark.parametrize("kw", [dict(),                                                  # as committed: Nfft 4096, comb 1, Np = K = 1024
+                                dict(Nfft=2048, N_carrier=512, comb=4, Constellation="64QAM"),
+                                dict(Nfft=1024, N_carrier=256, comb=8, Constellation="QPSK")])   # (the single-frame part needs a power-of-two N_carrier: its ifft is an OFDM_modulator call)
+def test_task5_sweep_tile_equals_oracle_and_call_by_call(drivers, ofdm, olib, kw):
+    """ofdm_task5_mse_tile: the MSE(SNR) sweep of Main_model_Task_5.m:303-346 as ONE device-resident
+    call -- Noise per point, conv, demodulator, LS / MMSE(h = ifft(H_LS)) / MP / OMP, four errors -- against the OracleLib replay
+    and the point-by-point form on the per-function entries (fp64: 1e-9), sharded over two ranks, and in fp32."""
+    snrs = np.array([0.0, 3.5, 10.0, 17.0, 20.0, 30.0])
+    t = drivers.task5.run(ofdm, SNRs=snrs, batched=True, **kw)["sweep"]["MSEs"]
+    p = drivers.task5.run(ofdm, SNRs=snrs, batched=False, **kw)["sweep"]["MSEs"]
+    o = drivers.task5.run(olib, SNRs=snrs, **kw)["sweep"]["MSEs"]
+    np.testing.assert_allclose(t, o, rtol=1e-9)
+    np.testing.assert_allclose(t, p, rtol=1e-9)
+    parts = [drivers.task5.run(ofdm, SNRs=snrs, batched=True, rank=r, world=2, **kw)["sweep"]["MSEs"] for r in range(2)]
+    assert np.array_equal(parts[0] + parts[1], t) and np.all(parts[0][:, 3:] == 0) and np.all(parts[1][:, :3] == 0)
+    f32 = drivers.task5.run(ofdm, SNRs=snrs, batched=True, precision="fp32", **kw)["sweep"]["MSEs"]
+    np.testing.assert_allclose(f32, o, rtol=2e-3)
+
+
 def test_task5_comb4_payload(drivers, ofdm, olib):
     kw = dict(Nfft=2048, N_carrier=512, comb=4, Constellation="64QAM", SNR_dB=26, SNRs=[20.0])
     g = drivers.task5.run(ofdm, **kw)
