@@ -611,6 +611,12 @@ struct FastPlanView {
   int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
   const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
   int m_pad;
+  const void* d_mt;        // fp32 MMSE mode, factored form: M^T [np][np_pad], the banded spline (w [bw][nc], c0 [nc]); else nullptr
+  int np_pad, sb_bw;
+  const float* d_sb_w;
+  const int32_t* d_sb_c0;
+  void** ws_v;             // [n_frames][np] MMSE estimate at the pilots
+  int64_t* ws_v_frames;    // frames that workspace holds
   void** ws_h;             // MMSE mode workspace: H [n_frames][n_carrier]
   void** ws_x;             // split path workspace: X(1..N_carrier, :) of every symbol [n_frames * n_symb][n_carrier]
   int64_t* ws_x_elems;
@@ -630,9 +636,34 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
 
 // ofdm_chain_mmse.hip: the MMSE estimator of a plan as one operator W^T [np][m_pad] and its batched application
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
-                        int m_pad, std::vector<c64>& wt);
+                        int m_pad, std::vector<c64>& wt, std::vector<c64>* mt_out = nullptr, int np_pad = 0,
+                        std::vector<double>* sop_out = nullptr);
+void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw);
+bool mmse_factored_usable(int np, int np_pad);
+int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, const void* y, void* v, void* hout,
+                      int np, int n_carrier, int64_t n_frames);
 template <typename T>
 int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames);
+
+// The MMSE estimate of every frame of a batch from its pilot LS values (P.ypil -> *pv.ws_h): fp32 plans with the factors
+// take H = Sop_banded * (M * Y), everything else the dense operator.  v [n_frames][np] lives in a plan-owned workspace.
+template <typename T>
+inline int mmse_stage_run(const FastPlanView& pv, const FastParams<T>& P, int64_t n_frames) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (pv.d_mt && mmse_factored_usable(pv.np, pv.np_pad)) {
+      int64_t& cap = *pv.ws_v_frames;
+      if (!*pv.ws_v || cap < n_frames) {
+        OFDM_HIP(hipStreamSynchronize(ctx().stream));
+        if (*pv.ws_v) { (void)hipFree(*pv.ws_v); *pv.ws_v = nullptr; }
+        OFDM_HIP(hipMalloc(pv.ws_v, sizeof(cx<float>) * (size_t)pv.np * n_frames));
+        cap = n_frames;
+      }
+      return mmse_factored_run(pv.d_mt, pv.np_pad, pv.d_sb_w, pv.d_sb_c0, pv.sb_bw, P.ypil, *pv.ws_v, *pv.ws_h, pv.np, pv.n_carrier,
+                               n_frames);
+    }
+  }
+  return mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames);
+}
 
 // ofdm_chain_wave.hip: the symbol stage with one wavefront per frame (Nfft 2048, fp32, N_carrier <= 512)
 bool chain_wave_supported(const FastPlanView& pv);

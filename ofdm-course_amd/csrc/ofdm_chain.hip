@@ -532,7 +532,8 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   if (!pl) return OFDM_OK;
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
                   pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x,
-                  pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop, pl->ws_raw};
+                  pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop, pl->ws_raw,
+                  pl->d_mt, pl->d_sb_w, pl->d_sb_c0, pl->ws_v};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : pl->ev_t4) if (e) (void)hipEventDestroy(e);
@@ -561,9 +562,13 @@ int ofdm_rx_plan_set_descrambler(ofdm_rx_plan* pl, const uint8_t* reg15) {
 int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double snr_db, int flags) {
   OFDM_TRY(ensure_init());
   OFDM_ARG(pl, "rx_plan_set_mmse: null plan");
+  auto drop_factors = [&]() {
+    for (void** q : {&pl->d_mt, &pl->d_sb_w, &pl->d_sb_c0}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  };
   if (!h || n_h <= 0) {                                   // back to OMP mode
     OFDM_HIP(hipStreamSynchronize(ctx().stream));
     if (pl->d_wt) { (void)hipFree(pl->d_wt); pl->d_wt = nullptr; }
+    drop_factors();
     return OFDM_OK;
   }
   OFDM_ARG((flags & OFDM_DEVICE) == 0, "rx_plan_set_mmse: h is a host array (the operator is built on the host)");
@@ -572,10 +577,31 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double s
   if (is_f64(flags)) std::memcpy(hh.data(), h, sizeof(c64) * (size_t)n_h);
   else for (int64_t i = 0; i < n_h; ++i) hh[i] = c64{(double)((const c32*)h)[i].x, (double)((const c32*)h)[i].y};
   const int m_pad = (pl->n_carrier + 15) & ~15;
-  std::vector<c64> wt;
-  OFDM_TRY(mmse_build_operator(hh.data(), n_h, snr_db, pl->pilot_loc.data(), pl->np, pl->n_carrier, m_pad, wt));
+  std::vector<c64> wt, mt;
+  std::vector<double> sop;
+  const int np_pad = (pl->np + 15) & ~15;
+  const bool factored = !pl->f64 && mmse_factored_usable(pl->np, np_pad);
+  OFDM_TRY(mmse_build_operator(hh.data(), n_h, snr_db, pl->pilot_loc.data(), pl->np, pl->n_carrier, m_pad, wt,
+                               factored ? &mt : nullptr, np_pad, factored ? &sop : nullptr));
   OFDM_HIP(hipStreamSynchronize(ctx().stream));
   if (pl->d_wt) { (void)hipFree(pl->d_wt); pl->d_wt = nullptr; }
+  drop_factors();
+  if (factored) {                                        // fp32: H = Sop_banded * (M * Y), ofdm_chain_mmse.hip
+    std::vector<c32> m32(mt.size());
+    for (size_t i = 0; i < mt.size(); ++i) m32[i] = c32{(float)mt[i].x, (float)mt[i].y};
+    std::vector<float> bw_w;
+    std::vector<int32_t> bw_c0;
+    int bw = 0;
+    mmse_band_spline(sop, pl->n_carrier, pl->np, bw_w, bw_c0, bw);
+    OFDM_HIP(hipMalloc(&pl->d_mt, sizeof(c32) * m32.size()));
+    OFDM_HIP(hipMemcpy(pl->d_mt, m32.data(), sizeof(c32) * m32.size(), hipMemcpyHostToDevice));
+    OFDM_HIP(hipMalloc(&pl->d_sb_w, sizeof(float) * bw_w.size()));
+    OFDM_HIP(hipMemcpy(pl->d_sb_w, bw_w.data(), sizeof(float) * bw_w.size(), hipMemcpyHostToDevice));
+    OFDM_HIP(hipMalloc(&pl->d_sb_c0, sizeof(int32_t) * bw_c0.size()));
+    OFDM_HIP(hipMemcpy(pl->d_sb_c0, bw_c0.data(), sizeof(int32_t) * bw_c0.size(), hipMemcpyHostToDevice));
+    pl->np_pad = np_pad;
+    pl->sb_bw = bw;
+  }
   if (pl->f64) {
     OFDM_HIP(hipMalloc(&pl->d_wt, sizeof(c64) * wt.size()));
     OFDM_HIP(hipMemcpy(pl->d_wt, wt.data(), sizeof(c64) * wt.size(), hipMemcpyHostToDevice));

@@ -470,7 +470,7 @@ static int launch_fast(const FastPlanView& pv, const void* tw, const void* rx, i
     if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
     // kernel 2
     if (mmse) {
-      OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
+      OFDM_TRY(mmse_stage_run<T>(pv, P, n_frames));
     } else {
       OFDM_TRY(omp_batch_run<T>(P, n_frames));
     }

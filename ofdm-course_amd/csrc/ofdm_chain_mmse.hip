@@ -20,8 +20,10 @@ namespace ofdm {
 using zc = std::complex<double>;
 
 // W^T [np][m_pad] (row index fastest: both kernels read 16 consecutive rows per pilot), rows >= n_carrier are zero.
+// Also returned: the two factors -- mt = M^T [np][np_pad] (M = I - Rpp^-1 / snr, the MMSE estimate AT the pilots) and the spline
+// operator sop [n_carrier x np] (column-major) -- for the factored application of the fp32 path (mmse_factored_run below).
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
-                        int m_pad, std::vector<c64>& wt) {
+                        int m_pad, std::vector<c64>& wt, std::vector<c64>* mt_out, int np_pad, std::vector<double>* sop_out) {
   OFDM_ARG(np >= 2 && np <= 512, "rx_plan_set_mmse: 2..512 pilots supported (the operator is built on the host)");
   OFDM_ARG(n_h >= 1, "rx_plan_set_mmse: empty impulse response");
   const double snr = std::pow(10.0, snr_db * 0.1);                                 // MMSE_CE.m:13
@@ -73,6 +75,12 @@ int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t*
   // W = Sop * M  (:38: interpolate(H_MMSE(1:Np), pilot_loc, N_carrier, 'spline'))
   std::vector<double> sop;                                                          // [n_carrier x np], column-major
   OFDM_TRY(build_interpolate_operator(pilot_loc, np, n_carrier, 's', sop));
+  if (mt_out) {
+    mt_out->assign((size_t)np * np_pad, c64{0, 0});
+    for (int j = 0; j < np; ++j)
+      for (int p = 0; p < np; ++p) (*mt_out)[(size_t)p * np_pad + j] = c64{M[(size_t)j * np + p].real(), M[(size_t)j * np + p].imag()};
+  }
+  if (sop_out) *sop_out = sop;
   wt.assign((size_t)np * m_pad, c64{0, 0});
   std::vector<zc> rowacc(np);
   for (int m = 0; m < n_carrier; ++m) {
@@ -98,6 +106,9 @@ int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t*
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// G = frame groups of 8 per wavefront: 8 (32 rows x 64 frames) for the tall dense operator, fewer for the small [Np x Np]
+// factor, whose grid would otherwise leave one workgroup per CU
+template <int G>
 __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* __restrict__ wt, const cx<float>* __restrict__ y,
                                                               cx<float>* __restrict__ hout, int np, int m_pad, int n_carrier,
                                                               int64_t n_frames) {
@@ -106,17 +117,17 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
   const int m0 = (blockIdx.y * 4 + wave) * 32;
   if (m0 >= m_pad) return;                                   // wavefront-uniform
   const bool two = m0 + 16 < m_pad;                          // wavefront-uniform: second carrier tile exists
-  const int64_t f0 = (int64_t)blockIdx.x * 64;
-  f32x4 acc[2][8];
+  const int64_t f0 = (int64_t)blockIdx.x * (8 * G);
+  f32x4 acc[2][G];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc[t][g] = f32x4{0, 0, 0, 0};
+    for (int g = 0; g < G; ++g) acc[t][g] = f32x4{0, 0, 0, 0};
   const cx<float>* ap[2] = {wt + m0 + i16, wt + (two ? m0 + 16 : m0) + i16};     // + p * m_pad
-  const float4* yp[8];
-  bool yv[8];
+  const float4* yp[G];
+  bool yv[G];
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
+  for (int g = 0; g < G; ++g) {
     const int64_t f = f0 + 8 * g + fsub;
     yv[g] = f < n_frames;
     yp[g] = reinterpret_cast<const float4*>(y + (yv[g] ? f : 0) * np + 2 * q);   // 16-byte aligned: np is even
@@ -124,8 +135,8 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
   // one k-step = 8 pilots: the lane holds pilots p0 + 2q and p0 + 2q + 1 (one 16-byte load per frame group), the first MFMA
   // round contracts the even ones, the second the odd ones
   cx<float> a[2][2];
-  float4 b[8];
-  auto fetch = [&](int p0, cx<float> (&aa)[2][2], float4 (&bb)[8]) {
+  float4 b[G];
+  auto fetch = [&](int p0, cx<float> (&aa)[2][2], float4 (&bb)[G]) {
     const int pa = p0 + 2 * q;
     const bool ok = pa < np;                                 // np % 4 == 0: the pair is valid or not as a whole
     const int pc = ok ? pa : 0;                              // loads are unconditional (clamped); the tail is zeroed in B
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
 #pragma unroll
     for (int t = 0; t < 2; ++t) { aa[t][0] = ap[t][row]; aa[t][1] = ap[t][row + m_pad]; }
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < G; ++g) {
       const float4 v = yp[g][(pc - 2 * q) >> 1];             // frames past the end read frame 0 and are never stored
       bb[g] = ok ? v : float4{0, 0, 0, 0};
     }
@@ -141,12 +152,12 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
   fetch(0, a, b);
   for (int p0 = 0; p0 < np; p0 += 8) {
     cx<float> an[2][2];
-    float4 bn[8];
+    float4 bn[G];
     fetch(p0 + 8 < np ? p0 + 8 : p0, an, bn);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
+      for (int g = 0; g < G; ++g) {
         const float yr = h ? b[g].z : b[g].x, yi = h ? b[g].w : b[g].y;
         const float b_re = cim ? yi : yr;                       // multiplies Re(W)
         const float b_im = cim ? yr : -yi;                      // multiplies Im(W)
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
 #pragma unroll
     for (int t = 0; t < 2; ++t) { a[t][0] = an[t][0]; a[t][1] = an[t][1]; }
 #pragma unroll
-    for (int g = 0; g < 8; ++g) b[g] = bn[g];
+    for (int g = 0; g < G; ++g) b[g] = bn[g];
   }
   // C: lane holds rows 4*(lane>>4)+r of column lane&15
   float* ho = reinterpret_cast<float*>(hout);
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
   for (int t = 0; t < 2; ++t) {
     if (t == 1 && !two) break;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < G; ++g) {
       const int64_t f = f0 + 8 * g + fsub;
       if (f < n_frames) {
 #pragma unroll
@@ -200,13 +211,101 @@ __global__ __launch_bounds__(256) void mmse_apply_valu_kernel(const cx<T>* __res
     if (f0 + j < n_frames) hout[(f0 + j) * n_carrier + m] = acc[j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Factored application (fp32 plans): H = Sop * (M * Y).  The dense W = Sop * M [N_carrier x Np] costs N_carrier / Np times the
+// flops of M [Np x Np] (4x at comb 4), and the spline operator of interpolate.m is banded for every practical purpose: the
+// weight of a not-a-knot spline falls by (2 - sqrt 3) per knot, so each row keeps the `bw` columns around its interval whose
+// weights reach 1e-10 of the row's largest (33 columns at 256 knots) -- below half an fp32 ulp of the result.
+//   (1) v[f][:] = M * Y[f][:]     mmse_apply_mfma_kernel on M^T [np][np_pad]          (8 np^2 flop per frame)
+//   (2) H[f][m] = sum_t w[t][m] v[f][c0[m] + t]     spline_band_kernel: v tile in LDS, weights t-major
+// fp64 plans keep the dense operator on VALU (parity mode: unchanged results).
+// ---------------------------------------------------------------------------------------------
+constexpr int SB_FT = 8;                                      // frames per workgroup
+__global__ __launch_bounds__(128) void spline_band_kernel(const float* __restrict__ w, const int32_t* __restrict__ c0, int bw,
+                                                          const cx<float>* __restrict__ v, cx<float>* __restrict__ hout, int nc,
+                                                          int np, int64_t n_frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
+  cx<float>* const vs = (cx<float>*)sb_smem;                  // [np][SB_FT]
+  const int64_t f0 = (int64_t)blockIdx.y * SB_FT;
+  for (int i = threadIdx.x; i < np * SB_FT; i += 128) {
+    const int f = i / np, j = i - f * np;                     // coalesced over the pilots of one frame
+    vs[j * SB_FT + f] = f0 + f < n_frames ? v[(f0 + f) * np + j] : mk<float>(0, 0);
+  }
+  __syncthreads();
+  const int m = blockIdx.x * 128 + threadIdx.x;
+  if (m >= nc) return;
+  const int j0 = c0[m];
+  cx<float> acc[SB_FT];
+#pragma unroll
+  for (int f = 0; f < SB_FT; ++f) acc[f] = mk<float>(0, 0);
+  for (int t = 0; t < bw; ++t) {
+    const float wt = w[(size_t)t * nc + m];
+    const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t) * SB_FT);
+#pragma unroll
+    for (int f2 = 0; f2 < SB_FT / 2; ++f2) {
+      const float4 x = row[f2];
+      acc[2 * f2].x = fmaf(wt, x.x, acc[2 * f2].x);     acc[2 * f2].y = fmaf(wt, x.y, acc[2 * f2].y);
+      acc[2 * f2 + 1].x = fmaf(wt, x.z, acc[2 * f2 + 1].x); acc[2 * f2 + 1].y = fmaf(wt, x.w, acc[2 * f2 + 1].y);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < SB_FT; ++f)
+    if (f0 + f < n_frames) hout[(f0 + f) * nc + m] = acc[f];
+}
+
+// rows of the spline operator cut to a common band width: w [bw][nc] (t-major), c0 [nc]
+void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw) {
+  std::vector<int> lo(nc), hi(nc);
+  bw = 1;
+  for (int m = 0; m < nc; ++m) {
+    double mx = 0;
+    for (int j = 0; j < np; ++j) mx = std::max(mx, std::fabs(sop[m + (size_t)j * nc]));
+    int a = np, b = -1;
+    for (int j = 0; j < np; ++j)
+      if (std::fabs(sop[m + (size_t)j * nc]) > 1e-10 * mx) { a = std::min(a, j); b = std::max(b, j); }
+    if (b < 0) { a = 0; b = 0; }
+    lo[m] = a; hi[m] = b;
+    bw = std::max(bw, b - a + 1);
+  }
+  bw = std::min(np, bw);
+  w.assign((size_t)bw * nc, 0.f);
+  c0.resize(nc);
+  for (int m = 0; m < nc; ++m) {
+    const int s0 = std::max(0, std::min(lo[m], np - bw));
+    c0[m] = s0;
+    for (int t = 0; t < bw; ++t) w[(size_t)t * nc + m] = (float)sop[m + (size_t)(s0 + t) * nc];
+  }
+}
+
+bool mmse_factored_usable(int np, int np_pad) { return np % 4 == 0 && np_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA") && !getenv("OFDM_MMSE_DENSE"); }
+
+int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, const void* y, void* v, void* hout,
+                      int np, int n_carrier, int64_t n_frames) {
+  hipStream_t st = ctx().stream;
+  int G = 4;                                                  // 32 rows x 32 frames per wavefront (G = 8 / 4 / 2 / 1 measured: 146 / 129 / 129 / 141 us per 8192 frames)
+  if (const char* e = getenv("OFDM_MMSE_G")) G = atoi(e);
+  const unsigned gy = (unsigned)(((np_pad + 31) / 32 + 3) / 4);
+  auto launch = [&](auto kern, int g) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_frames + 8 * g - 1) / (8 * g)), gy), dim3(256), 0, st, (const cx<float>*)mt,
+                       (const cx<float>*)y, (cx<float>*)v, np, np_pad, np, n_frames);
+  };
+  if (G >= 8) launch(mmse_apply_mfma_kernel<8>, 8);
+  else if (G >= 4) launch(mmse_apply_mfma_kernel<4>, 4);
+  else if (G >= 2) launch(mmse_apply_mfma_kernel<2>, 2);
+  else launch(mmse_apply_mfma_kernel<1>, 1);
+  const dim3 g2((unsigned)((n_carrier + 127) / 128), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
+  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(128), sizeof(cx<float>) * (size_t)np * SB_FT, st, sb_w, sb_c0, bw, (const cx<float>*)v,
+                     (cx<float>*)hout, n_carrier, np, n_frames);
+  return check_launch("mmse factored stage");
+}
+
 template <typename T>
 int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames) {
   hipStream_t st = ctx().stream;
   if constexpr (std::is_same<T, float>::value) {
     if (np % 4 == 0 && m_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA")) {
       const dim3 grid((unsigned)((n_frames + 63) / 64), (unsigned)(((m_pad + 31) / 32 + 3) / 4));
-      hipLaunchKernelGGL(mmse_apply_mfma_kernel, grid, dim3(256), 0, st, (const cx<float>*)wt, (const cx<float>*)y,
+      hipLaunchKernelGGL(mmse_apply_mfma_kernel<8>, grid, dim3(256), 0, st, (const cx<float>*)wt, (const cx<float>*)y,
                          (cx<float>*)hout, np, m_pad, n_carrier, n_frames);
       return check_launch("mmse_apply_mfma_kernel");
     }

@@ -385,7 +385,7 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
     OFDM_TRY(check_launch("pilot_ls_kernel"));
   }
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
-  if (mmse) OFDM_TRY(mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames));
+  if (mmse) OFDM_TRY(mmse_stage_run<T>(pv, P, n_frames));
   else OFDM_TRY(omp_batch_run<T>(P, n_frames));
   if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
   OFDM_TRY(eq_demap_run<T>(pv, P, xk, pv.n_carrier, mmse, n_frames, bits, ref, errs, h_out, idx_out, nullptr, 0, 0));
