@@ -670,6 +670,11 @@ bool chain_wave_supported(const FastPlanView& pv);
 int chain_wave_symbols_run(const FastPlanView& pv, const FastParams<float>& P, const void* rx, int64_t n_frames, void* bits,
                            const void* ref, void* errs, void* h_out, void* idx_out);
 
+// ofdm_chain_coop.hip: the symbol stage for Nfft 8192 (fp32, N_carrier <= 2048) in one pass over the samples
+bool chain_coop_supported(const FastPlanView& pv);
+int chain_coop_symbols_run(const FastPlanView& pv, const FastParams<float>& P, const void* rx, int64_t n_frames, void* bits,
+                           const void* ref, void* errs, void* h_out, void* idx_out);
+
 // ofdm_chain_pilot.hip: symbol-1 transform + OMP of every frame in one launch (comb pilots, taps <= OMP_RT)
 template <typename T>
 int pilot_omp_run(const FastParams<T>& P, int nfft, bool prune2, int lg_up, const void* rx, int64_t n_frames);

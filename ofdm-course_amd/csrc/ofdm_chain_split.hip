@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
                                                              int64_t n_symb, int t_guard, int n_keep,
                                                              cx<T>* __restrict__ ypil /* or null */, const int32_t* __restrict__ pc0,
                                                              const cx<T>* __restrict__ pilots, int np, int n_symb_frame,
-                                                             const int16_t* __restrict__ drole /* or null: every row is wanted */) {
+                                                             const int16_t* __restrict__ drole /* or null: every row is wanted */,
+                                                             int64_t sym_stride /* samples between processed symbols */) {
   constexpr int NW = 8;
   constexpr int psh = 4;                                       // staging pad: one element every 16
   constexpr int NOUT = PRUNE2 ? 2 : 8;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
   }
   __syncthreads();
   for (int64_t s = blockIdx.x; s < n_symb; s += gridDim.x) {
-    const cx<T>* src = y + s * (int64_t)(8192 + t_guard) + t_guard;
+    const cx<T>* src = y + s * sym_stride + t_guard;
     const bool first_of_frame = (unsigned)s % (unsigned)n_symb_frame == 0u;
     cx<T> a[8], b[8];
 #pragma unroll
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 4 ? 4 : 2) void demod_keep8192_ke
 
 template <typename T>
 static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guard, int n_keep, void* ypil, const int32_t* pc0,
-                              const void* pilots, int np, int n_symb_frame, const void* drole) {
+                              const void* pilots, int np, int n_symb_frame, const void* drole, int64_t sym_stride = 0) {
+  if (sym_stride == 0) sym_stride = 8192 + t_guard;              // every symbol of the stream; a frame length = first symbols only
   const void *tw4 = nullptr, *tw8 = nullptr;
   OFDM_ARG(n_symb < (int64_t)1 << 31, "rx_chain_task5: more than 2^31 symbols in one call");
   OFDM_TRY(get_twiddles(4096, std::is_same<T, double>::value, &tw4));
@@ -298,7 +300,7 @@ static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guar
     const unsigned grid = (unsigned)std::min<int64_t>(n_symb, (int64_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), dyn, ctx().stream, (const cx<T>*)y, (cx<T>*)x, (const cx<T>*)tw4,
                        (const cx<T>*)tw8, n_symb, t_guard, n_keep, (cx<T>*)ypil, pc0, (const cx<T>*)pilots, np, n_symb_frame,
-                       (const int16_t*)drole);
+                       (const int16_t*)drole, sym_stride);
     return check_launch("demod_keep8192_kernel");
   };
   if (n_keep <= 2048) return launch(demod_keep8192_kernel<T, true>);
@@ -355,6 +357,24 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   FastParams<T> P;
   OFDM_TRY(fast_params_prepare<T>(pv, tw, n_frames, P));
   const bool mmse = pv.d_wt != nullptr;
+  if constexpr (std::is_same<T, float>::value) {
+    if (chain_coop_supported(pv)) {
+      // one pass over the samples (ofdm_chain_coop.hip): the first symbol of every frame -> stash + pilot LS values, the
+      // estimator, then every other symbol transformed, equalised, sliced, packed and counted without an X round trip
+      hipStream_t st = ctx().stream;
+      if (pv.fused_out) *pv.fused_out = 0;
+      if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[0], st));
+      OFDM_TRY(demod_keep8192_run<T>(rx, P.stash, n_frames, pv.t_guard, pv.n_carrier, (void*)P.ypil, d_pc0, P.pilots, pv.np, 1, nullptr,
+                                     (int64_t)(8192 + pv.t_guard) * pv.n_symb));
+      if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[1], st));
+      if (mmse) OFDM_TRY(mmse_stage_run<T>(pv, P, n_frames));
+      else OFDM_TRY(omp_batch_run<T>(P, n_frames));
+      if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
+      OFDM_TRY(chain_coop_symbols_run(pv, P, rx, n_frames, bits, ref, errs, h_out, idx_out));
+      if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
+      return OFDM_OK;
+    }
+  }
   const int64_t need = n_frames * pv.n_symb * (int64_t)pv.n_carrier;
   if (*pv.ws_x_elems < need) {
     OFDM_HIP(hipStreamSynchronize(ctx().stream));
