@@ -13,6 +13,11 @@
 //      four rounds of eight kj across the lanes, last radix-8 pruned to 2 outputs), equalises, slices and writes code bytes
 //   C. the raw samples of the NEXT symbol are requested right after step A into registers of their own, so they travel during B
 //   D. wavefront 0 packs the previous symbol's codes and counts errors while the others are in A / B of the next symbol
+// Measured (3072 frames of 14 symbols, C5): 0.75 ms for this stage at two workgroups per CU against 1.31 ms at one -- it is bound
+// by latency (VALU issue 45 %, LDS 24 %, 61 % of the wavefront-cycles waiting), and the 48 KB hand-over buffer is what keeps a
+// third workgroup off the CU.  Handing the residues over one at a time through 16 KB (44.7 KB per workgroup, 168 VGPRs) was
+// built and measured: 220 spilled registers (the three y_s of a quarter live beside the sample array) and six barriers per
+// symbol -- 1.63 ms.  A barrier right behind the hand-over reads instead of behind the transforms: 0.79 ms.
 // With comb-4 pilots (1 : 4 : end) the sub-transform s = 0 holds nothing but pilot carriers: its wavefront skips step B on data
 // symbols (and is the one that packs).  H = fft(h_est) on the carriers is ONE MORE transform of the same kind per frame (the
 // taps scattered into a 512-sample vector), computed in place of a symbol; the first symbol's rows come from the stash of the
