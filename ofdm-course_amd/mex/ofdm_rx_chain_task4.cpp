@@ -3,10 +3,11 @@
 // equalize_signal -> get_payload -> demapping) and, with ref_bits, BER_func's numerator.
 //
 //   [bits, TgPosition, FreqOffset, IFO, status, errors, H_est] = ofdm_rx_chain_task4(Rx, Nfft, T_guard, N_carrier, ...
-//        pilotCarriers, dataCarriers, pilotValues, Constellation, Time_Desync, Freq_Desync, MP_Desync, ref_bits)
+//        pilotCarriers, dataCarriers, pilotValues, Constellation, Time_Desync, Freq_Desync, MP_Desync, ref_bits, Register)
 //   Rx   [(Nfft+T_guard)*N_symb x n_frames] complex, one received frame per column; the three flags are the script's
-//        switches of :34-36; ref_bits optional [bits_per_frame x n_frames] (the SCRAMBLED bits: the per-frame DeScrambler of
-//        :354-364 stays the caller's)
+//        switches of :34-36; ref_bits optional [bits_per_frame x n_frames]; Register optional [1 x 15]: with it the frames go
+//        through the per-frame DeScrambler of :354-364 before `bits` / `errors` (ref_bits = the payload before the Scrambler),
+//        without it `bits` are the demapped (scrambled) bits and ref_bits the scrambled ones
 //   status: 0 ok, 1 AutoCorrFunction's catch branch (TgPosition 65), -1 no IFO line above 0.77, -2 TgPosition out of range
 #include "ofdm_mex_common.hpp"
 using namespace ofdm_mex;
@@ -20,7 +21,7 @@ void at_exit_chain() { drop_plan(); ofdm_shutdown(); }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   const char* fn = "ofdm_rx_chain_task4";
-  need(nrhs == 11 || nrhs == 12, fn, "eleven or twelve inputs expected");
+  need(nrhs >= 11 && nrhs <= 13, fn, "eleven to thirteen inputs expected");
   ensure_init();
   mexAtExit(at_exit_chain);
   const int nfft = (int)get_scalar(prhs[1], fn), tg = (int)get_scalar(prhs[2], fn), nc = (int)get_scalar(prhs[3], fn);
@@ -56,7 +57,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   const size_t frame_bits = dc.size() * (size_t)n_symb * (size_t)bps;
   CBuf rx = get_complex(prhs[0], fn);
   std::vector<uint8_t> ref_packed;
-  const bool have_ref = nrhs == 12 && mxGetNumberOfElements(prhs[11]) > 0;
+  const bool have_ref = nrhs >= 12 && mxGetNumberOfElements(prhs[11]) > 0;
   if (have_ref) {
     const std::vector<uint8_t> rb = get_bits(prhs[11], fn);
     need(rb.size() == frame_bits * n_frames, fn, "ref_bits must be [bits_per_frame x n_frames]");
@@ -64,6 +65,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     for (size_t f = 0; f < n_frames; ++f)
       for (size_t i = 0; i < frame_bits; ++i)
         if (rb[f * frame_bits + i]) ref_packed[f * fb + i / 8] |= (uint8_t)(0x80u >> (i % 8));
+  }
+  // optional Register (1 x 15, Main_model_Task_4.m:44): the per-frame DeScrambler of :354-364 inside the call; [] = off
+  if (nrhs == 13 && mxGetNumberOfElements(prhs[12]) > 0) {
+    const std::vector<uint8_t> reg = get_bits(prhs[12], fn);
+    need(reg.size() == 15, fn, "Register must have 15 entries");
+    check(ofdm_rx_plan_set_descrambler(g_plan, reg.data()), fn);
+  } else {
+    check(ofdm_rx_plan_set_descrambler(g_plan, nullptr), fn);
   }
   std::vector<uint8_t> bits_packed((size_t)fb * n_frames);
   std::vector<uint32_t> errs(n_frames);

@@ -3,11 +3,13 @@
 // OMP_estimate -> equalize_signal -> get_payload -> demapping) and, with ref_bits, BER_func's numerator.
 //
 //   [bits, H_OMP, index, errors] = ofdm_rx_chain_task5(Rx, Nfft, T_guard, N_carrier, pilotCarriers, dataCarriers, ...
-//                                                      pilotValues, K, dominant_taps, Constellation, ref_bits)
+//                                                      pilotValues, K, dominant_taps, Constellation, ref_bits, Register)
 //   Rx            [(Nfft+T_guard)*N_symb x n_frames] complex: every column one received frame (Rx_OFDM_mapped_carriers of :160-166)
 //   pilotValues   [Np x N_symb] (or [Np x 1]): the pilot column of the first symbol is what the estimator uses (:190)
 //   K             columns of the dictionary F(:,1:K) (:182-184); dominant_taps (:187)
 //   ref_bits      optional [bits_per_frame x n_frames] 0/1: the transmitted payload
+//   Register      optional [1 x 15]: the frames are descrambled (DeScrambler, register reset per frame, Main_model_Task_5.m:257-274)
+//                 before `bits` and `errors` -- ref_bits then holds the payload BEFORE the Scrambler
 //   bits          [bits_per_frame x n_frames] 0/1 demapped bits (get_payload order: column-major over [Nd x N_symb])
 //   H_OMP         [N_carrier x n_frames];  index [dominant_taps x n_frames] (1-based picks, 0 = unused);  errors [1 x n_frames]
 // N_symb is taken from size(Rx,1).  The plan (carrier tables, dictionary in closed form, Gram table) is built on the first
@@ -24,7 +26,7 @@ void at_exit_chain() { drop_plan(); ofdm_shutdown(); }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   const char* fn = "ofdm_rx_chain_task5";
-  need(nrhs == 10 || nrhs == 11, fn, "ten or eleven inputs expected");
+  need(nrhs >= 10 && nrhs <= 12, fn, "ten to twelve inputs expected");
   ensure_init();
   mexAtExit(at_exit_chain);
   const int nfft = (int)get_scalar(prhs[1], fn), tg = (int)get_scalar(prhs[2], fn), nc = (int)get_scalar(prhs[3], fn);
@@ -66,11 +68,19 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (bits01[f * frame_bits + i]) packed[f * fb + i / 8] |= (uint8_t)(0x80u >> (i % 8));
   };
   std::vector<uint8_t> ref_packed;
-  const bool have_ref = nrhs == 11 && mxGetNumberOfElements(prhs[10]) > 0;
+  const bool have_ref = nrhs >= 11 && mxGetNumberOfElements(prhs[10]) > 0;
   if (have_ref) {
     const std::vector<uint8_t> rb = get_bits(prhs[10], fn);
     need(rb.size() == frame_bits * n_frames, fn, "ref_bits must be [bits_per_frame x n_frames]");
     pack(rb, ref_packed);
+  }
+  // optional Register (1 x 15, Main_model_Task_5.m:55): DeScrambler per frame before bits / errors (:257-274); [] = off
+  if (nrhs == 12 && mxGetNumberOfElements(prhs[11]) > 0) {
+    const std::vector<uint8_t> reg = get_bits(prhs[11], fn);
+    need(reg.size() == 15, fn, "Register must have 15 entries");
+    check(ofdm_rx_plan_set_descrambler(g_plan, reg.data()), fn);
+  } else {
+    check(ofdm_rx_plan_set_descrambler(g_plan, nullptr), fn);
   }
   std::vector<uint8_t> bits_packed((size_t)fb * n_frames);
   std::vector<uint32_t> errs(n_frames);

@@ -119,4 +119,4 @@ def test_mex_gateways_typecheck_against_the_header():
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "check_mex_syntax.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     names = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "ofdm-course_amd", "mex")) if f.endswith(".cpp"))
-    assert len(names) == 31 and "ofdm_rx_chain_task4" in names and "ofdm_rx_chain_task5" in names and "ofdm_task5_part2_tile" in names and "OMP_estimate" in names and "AutoCorrFunction" in names and "calculate_window_PAPR" in names
+    assert len(names) == 32 and "ofdm_rx_chain_task4" in names and "ofdm_rx_chain_task5" in names and "ofdm_task5_part2_tile" in names and "ofdm_task5_mse_tile" in names and "OMP_estimate" in names and "AutoCorrFunction" in names and "calculate_window_PAPR" in names

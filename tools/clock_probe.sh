@@ -5,7 +5,7 @@ out=$1; mkdir -p $out; root=$PWD; python ofdm-course_amd/build.py --diag > $out/
  cd /tmp && export TMPDIR=/tmp && cd $root
 for v in normal abl; do
   if [ $v = abl ]; then export OFDM_WAVE_ABL=1 OFDM_BENCH_ALLOW_DIAG=1 OFDM_LIB_PATH=$root/ofdm-course_amd/libofdm_mi355x_diag.so; else unset OFDM_WAVE_ABL OFDM_BENCH_ALLOW_DIAG OFDM_LIB_PATH; fi
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/$v -- python bench.py --no-cpu --steps 200 --warmup 20 > $out/$v.log 2>&1 || echo "pass $v failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/$v -- python bench.py --no-cpu --no-f64 --no-secondary --steps 200 --warmup 20 > $out/$v.log 2>&1 || echo "pass $v failed"
 done
 python - <<PY
 import csv, glob
