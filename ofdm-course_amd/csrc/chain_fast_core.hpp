@@ -612,7 +612,7 @@ struct FastPlanView {
   const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
   int m_pad;
   const void* d_mt;        // fp32 MMSE mode, factored form: M^T [np][np_pad], the banded spline (w [bw][nc], c0 [nc]); else nullptr
-  int np_pad, sb_bw;
+  int np_pad, sb_bw, sb_span;
   const float* d_sb_w;
   const int32_t* d_sb_c0;
   void** ws_v;             // [n_frames][np] MMSE estimate at the pilots
@@ -638,10 +638,10 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
 int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t* pilot_loc, int np, int n_carrier,
                         int m_pad, std::vector<c64>& wt, std::vector<c64>* mt_out = nullptr, int np_pad = 0,
                         std::vector<double>* sop_out = nullptr);
-void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw);
+void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw, int& span);
 bool mmse_factored_usable(int np, int np_pad);
-int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, const void* y, void* v, void* hout,
-                      int np, int n_carrier, int64_t n_frames);
+int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* y, void* v,
+                      void* hout, int np, int n_carrier, int64_t n_frames);
 template <typename T>
 int mmse_apply_run(const void* wt, const void* y, void* hout, int np, int m_pad, int n_carrier, int64_t n_frames);
 
@@ -658,8 +658,8 @@ inline int mmse_stage_run(const FastPlanView& pv, const FastParams<T>& P, int64_
         OFDM_HIP(hipMalloc(pv.ws_v, sizeof(cx<float>) * (size_t)pv.np * n_frames));
         cap = n_frames;
       }
-      return mmse_factored_run(pv.d_mt, pv.np_pad, pv.d_sb_w, pv.d_sb_c0, pv.sb_bw, P.ypil, *pv.ws_v, *pv.ws_h, pv.np, pv.n_carrier,
-                               n_frames);
+      return mmse_factored_run(pv.d_mt, pv.np_pad, pv.d_sb_w, pv.d_sb_c0, pv.sb_bw, pv.sb_span, P.ypil, *pv.ws_v, *pv.ws_h, pv.np,
+                               pv.n_carrier, n_frames);
     }
   }
   return mmse_apply_run<T>(pv.d_wt, P.ypil, *pv.ws_h, pv.np, pv.m_pad, pv.n_carrier, n_frames);

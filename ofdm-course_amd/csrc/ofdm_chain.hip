@@ -591,8 +591,8 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double s
     for (size_t i = 0; i < mt.size(); ++i) m32[i] = c32{(float)mt[i].x, (float)mt[i].y};
     std::vector<float> bw_w;
     std::vector<int32_t> bw_c0;
-    int bw = 0;
-    mmse_band_spline(sop, pl->n_carrier, pl->np, bw_w, bw_c0, bw);
+    int bw = 0, span = 0;
+    mmse_band_spline(sop, pl->n_carrier, pl->np, bw_w, bw_c0, bw, span);
     OFDM_HIP(hipMalloc(&pl->d_mt, sizeof(c32) * m32.size()));
     OFDM_HIP(hipMemcpy(pl->d_mt, m32.data(), sizeof(c32) * m32.size(), hipMemcpyHostToDevice));
     OFDM_HIP(hipMalloc(&pl->d_sb_w, sizeof(float) * bw_w.size()));
@@ -601,6 +601,7 @@ int ofdm_rx_plan_set_mmse(ofdm_rx_plan* pl, const void* h, int64_t n_h, double s
     OFDM_HIP(hipMemcpy(pl->d_sb_c0, bw_c0.data(), sizeof(int32_t) * bw_c0.size(), hipMemcpyHostToDevice));
     pl->np_pad = np_pad;
     pl->sb_bw = bw;
+    pl->sb_span = span;
   }
   if (pl->f64) {
     OFDM_HIP(hipMalloc(&pl->d_wt, sizeof(c64) * wt.size()));

@@ -220,27 +220,38 @@ __global__ __launch_bounds__(256) void mmse_apply_valu_kernel(const cx<T>* __res
 //   (2) H[f][m] = sum_t w[t][m] v[f][c0[m] + t]     spline_band_kernel: v tile in LDS, weights t-major
 // fp64 plans keep the dense operator on VALU (parity mode: unchanged results).
 // ---------------------------------------------------------------------------------------------
-constexpr int SB_FT = 8;                                      // frames per workgroup
-__global__ __launch_bounds__(128) void spline_band_kernel(const float* __restrict__ w, const int32_t* __restrict__ c0, int bw,
-                                                          const cx<float>* __restrict__ v, cx<float>* __restrict__ hout, int nc,
-                                                          int np, int64_t n_frames) {
+constexpr int SB_FT = 32;                                     // frames per workgroup
+constexpr int SB_ROWS = 128;                                  // rows (carriers) per workgroup = threads
+constexpr int SB_VS = SB_FT + 2;                              // v tile row stride: 272 B, so the 16 windows a wavefront's rows start in
+                                                              // read 16 different 16-byte bank groups (256 B apart they were a 16-way conflict: 147 us)
+// One workgroup = SB_ROWS carriers x SB_FT frames.  The rows of a workgroup use the columns c_lo .. c_lo + span - 1 only (their
+// bands overlap: 128 carriers at comb 4 span 32 knots + the band width), so the v tile in LDS is [span][SB_FT]; the rows' weights
+// [bw][SB_ROWS] sit in LDS as well -- the inner loop touches LDS only.  (First form: 8 frames per workgroup, the weight of every
+// step loaded from L2 inside the loop -- 33 dependent L2 latencies per thread: 74 us per 8192 frames.)
+__global__ __launch_bounds__(SB_ROWS) void spline_band_kernel(const float* __restrict__ w, const int32_t* __restrict__ c0, int bw, int span,
+                                                              const cx<float>* __restrict__ v, cx<float>* __restrict__ hout, int nc,
+                                                              int np, int64_t n_frames) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
-  cx<float>* const vs = (cx<float>*)sb_smem;                  // [np][SB_FT]
+  cx<float>* const vs = (cx<float>*)sb_smem;                  // [span][SB_VS]
+  float* const ws = (float*)(vs + (size_t)span * SB_VS);      // [bw][SB_ROWS]
+  const int m0 = blockIdx.x * SB_ROWS, m = m0 + threadIdx.x;
   const int64_t f0 = (int64_t)blockIdx.y * SB_FT;
-  for (int i = threadIdx.x; i < np * SB_FT; i += 128) {
-    const int f = i / np, j = i - f * np;                     // coalesced over the pilots of one frame
-    vs[j * SB_FT + f] = f0 + f < n_frames ? v[(f0 + f) * np + j] : mk<float>(0, 0);
+  const int c_lo = c0[m0];                                    // c0 is non-decreasing in m
+  for (int i = threadIdx.x; i < span * SB_FT; i += SB_ROWS) {
+    const int f = i / span, j = i - f * span;                 // coalesced over the pilots of one frame
+    const bool ok = f0 + f < n_frames && c_lo + j < np;
+    vs[j * SB_VS + f] = ok ? v[(f0 + f) * np + c_lo + j] : mk<float>(0, 0);
   }
+  for (int t = 0; t < bw; ++t) ws[t * SB_ROWS + threadIdx.x] = m < nc ? w[(size_t)t * nc + m] : 0.f;
   __syncthreads();
-  const int m = blockIdx.x * 128 + threadIdx.x;
   if (m >= nc) return;
-  const int j0 = c0[m];
+  const int j0 = c0[m] - c_lo;
   cx<float> acc[SB_FT];
 #pragma unroll
   for (int f = 0; f < SB_FT; ++f) acc[f] = mk<float>(0, 0);
   for (int t = 0; t < bw; ++t) {
-    const float wt = w[(size_t)t * nc + m];
-    const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t) * SB_FT);
+    const float wt = ws[t * SB_ROWS + threadIdx.x];
+    const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t) * SB_VS);
 #pragma unroll
     for (int f2 = 0; f2 < SB_FT / 2; ++f2) {
       const float4 x = row[f2];
@@ -254,9 +265,10 @@ __global__ __launch_bounds__(128) void spline_band_kernel(const float* __restric
 }
 
 // rows of the spline operator cut to a common band width: w [bw][nc] (t-major), c0 [nc]
-void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw) {
+// span = the largest number of columns the SB_ROWS rows of one workgroup of spline_band_kernel touch
+void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw, int& span) {
+  // columns [lo, hi] of a row that reach 1e-10 of its largest weight (a row AT a knot is a unit vector: lo = hi = the knot)
   std::vector<int> lo(nc), hi(nc);
-  bw = 1;
   for (int m = 0; m < nc; ++m) {
     double mx = 0;
     for (int j = 0; j < np; ++j) mx = std::max(mx, std::fabs(sop[m + (size_t)j * nc]));
@@ -265,22 +277,30 @@ void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vecto
       if (std::fabs(sop[m + (size_t)j * nc]) > 1e-10 * mx) { a = std::min(a, j); b = std::max(b, j); }
     if (b < 0) { a = 0; b = 0; }
     lo[m] = a; hi[m] = b;
-    bw = std::max(bw, b - a + 1);
   }
-  bw = std::min(np, bw);
-  w.assign((size_t)bw * nc, 0.f);
+  // first column of a row's window = the smallest lo of this and every later row: non-decreasing in m (the kernel takes a
+  // workgroup's column range from its first and last row) and never to the right of the row's own first column
   c0.resize(nc);
-  for (int m = 0; m < nc; ++m) {
-    const int s0 = std::max(0, std::min(lo[m], np - bw));
-    c0[m] = s0;
-    for (int t = 0; t < bw; ++t) w[(size_t)t * nc + m] = (float)sop[m + (size_t)(s0 + t) * nc];
+  int smin = np;
+  for (int m = nc - 1; m >= 0; --m) { smin = std::min(smin, lo[m]); c0[m] = smin; }
+  bw = 1;
+  for (int m = 0; m < nc; ++m) bw = std::max(bw, hi[m] - c0[m] + 1);
+  bw = std::min(np, bw);
+  for (int m = 0; m < nc; ++m) c0[m] = std::max(0, std::min(c0[m], np - bw));
+  w.assign((size_t)bw * nc, 0.f);
+  for (int m = 0; m < nc; ++m)
+    for (int t = 0; t < bw; ++t) w[(size_t)t * nc + m] = (float)sop[m + (size_t)(c0[m] + t) * nc];
+  span = bw;
+  for (int m0 = 0; m0 < nc; m0 += 128) {
+    const int last = std::min(nc, m0 + 128) - 1;
+    span = std::max(span, c0[last] + bw - c0[m0]);
   }
 }
 
 bool mmse_factored_usable(int np, int np_pad) { return np % 4 == 0 && np_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA") && !getenv("OFDM_MMSE_DENSE"); }
 
-int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, const void* y, void* v, void* hout,
-                      int np, int n_carrier, int64_t n_frames) {
+int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* y, void* v,
+                      void* hout, int np, int n_carrier, int64_t n_frames) {
   hipStream_t st = ctx().stream;
   int G = 4;                                                  // 32 rows x 32 frames per wavefront (G = 8 / 4 / 2 / 1 measured: 146 / 129 / 129 / 141 us per 8192 frames)
   if (const char* e = getenv("OFDM_MMSE_G")) G = atoi(e);
@@ -293,9 +313,10 @@ int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32
   else if (G >= 4) launch(mmse_apply_mfma_kernel<4>, 4);
   else if (G >= 2) launch(mmse_apply_mfma_kernel<2>, 2);
   else launch(mmse_apply_mfma_kernel<1>, 1);
-  const dim3 g2((unsigned)((n_carrier + 127) / 128), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
-  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(128), sizeof(cx<float>) * (size_t)np * SB_FT, st, sb_w, sb_c0, bw, (const cx<float>*)v,
-                     (cx<float>*)hout, n_carrier, np, n_frames);
+  const dim3 g2((unsigned)((n_carrier + SB_ROWS - 1) / SB_ROWS), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
+  const size_t lds = sizeof(cx<float>) * (size_t)span * SB_VS + sizeof(float) * (size_t)bw * SB_ROWS;
+  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(SB_ROWS), lds, st, sb_w, sb_c0, bw, span, (const cx<float>*)v, (cx<float>*)hout,
+                     n_carrier, np, n_frames);
   return check_launch("mmse factored stage");
 }
 

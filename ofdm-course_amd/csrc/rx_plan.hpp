@@ -19,7 +19,7 @@ struct ofdm_rx_plan {
   void* d_wt = nullptr;    // MMSE mode (ofdm_rx_plan_set_mmse): W^T [np][m_pad]
   int m_pad = 0;
   void *d_mt = nullptr, *d_sb_w = nullptr, *d_sb_c0 = nullptr, *ws_v = nullptr;   // fp32 MMSE mode, factored: M^T, banded spline, v workspace
-  int np_pad = 0, sb_bw = 0;
+  int np_pad = 0, sb_bw = 0, sb_span = 0;
   int64_t ws_v_frames = 0;
   std::vector<int32_t> pilot_loc;      // 1-based, as given
   int data_mod4 = 15;                  // bit r set: some data carrier has (0-based) index = r mod 4
@@ -74,7 +74,7 @@ inline void make_plan_view(ofdm_rx_plan* pl, ofdm::FastPlanView& pv) {
   pv.comb_m = pl->comb_m;
   pv.fused_out = &pl->last_fused;
   pv.d_wt = pl->d_wt; pv.m_pad = pl->m_pad; pv.ws_h = &pl->ws_h;
-  pv.d_mt = pl->d_mt; pv.np_pad = pl->np_pad; pv.sb_bw = pl->sb_bw; pv.d_sb_w = (const float*)pl->d_sb_w;
+  pv.d_mt = pl->d_mt; pv.np_pad = pl->np_pad; pv.sb_bw = pl->sb_bw; pv.sb_span = pl->sb_span; pv.d_sb_w = (const float*)pl->d_sb_w;
   pv.d_sb_c0 = (const int32_t*)pl->d_sb_c0; pv.ws_v = &pl->ws_v; pv.ws_v_frames = &pl->ws_v_frames;
   pv.ws_x = &pl->ws_x; pv.ws_x_elems = &pl->ws_x_elems;
   pv.data_mod4 = pl->data_mod4;
