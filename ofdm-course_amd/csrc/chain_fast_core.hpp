@@ -639,6 +639,8 @@ int mmse_build_operator(const c64* h, int64_t n_h, double snr_db, const int32_t*
                         int m_pad, std::vector<c64>& wt, std::vector<c64>* mt_out = nullptr, int np_pad = 0,
                         std::vector<double>* sop_out = nullptr);
 void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw, int& span);
+int spline_band_run(const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* v, void* hout, int np, int n_carrier,
+                    int64_t n_frames);      // 1 = not taken (LDS), 0 ok, < 0 error
 bool mmse_factored_usable(int np, int np_pad);
 int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* y, void* v,
                       void* hout, int np, int n_carrier, int64_t n_frames);

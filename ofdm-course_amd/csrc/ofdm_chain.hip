@@ -533,7 +533,7 @@ int ofdm_rx_plan_destroy(ofdm_rx_plan* pl) {
   void* ptrs[] = {pl->d_prole, pl->d_drole, pl->d_pilots, pl->d_sct, pl->d_gram, pl->d_pc0,
                   pl->ws_stash, pl->ws_ypil, pl->ws_tapidx, pl->ws_tapx, pl->ws_h, pl->d_wt, pl->ws_x,
                   pl->ws_gen, pl->d_dict, pl->ws_t4, pl->d_t4_tx, pl->d_t4_w, pl->d_p2_sop, pl->ws_raw,
-                  pl->d_mt, pl->d_sb_w, pl->d_sb_c0, pl->ws_v};
+                  pl->d_mt, pl->d_sb_w, pl->d_sb_c0, pl->ws_v, pl->d_t4_bw, pl->d_t4_bc0};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : pl->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : pl->ev_t4) if (e) (void)hipEventDestroy(e);

@@ -297,6 +297,18 @@ void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vecto
   }
 }
 
+// the banded product on its own (the Task-4 receiver's estimate_channel.m:8 on fp32 plans): H[f][m] = sum_t w[t][m] v[f][c0[m] + t]
+int spline_band_run(const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* v, void* hout, int np, int n_carrier,
+                    int64_t n_frames) {
+  const dim3 g2((unsigned)((n_carrier + SB_ROWS - 1) / SB_ROWS), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
+  const size_t lds = sizeof(cx<float>) * (size_t)span * SB_VS + sizeof(float) * (size_t)bw * SB_ROWS;
+  if (lds > 150 * 1024) return 1;                              // not taken: the caller keeps its dense product
+  (void)hipFuncSetAttribute((const void*)spline_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(SB_ROWS), lds, ctx().stream, sb_w, sb_c0, bw, span, (const cx<float>*)v,
+                     (cx<float>*)hout, n_carrier, np, n_frames);
+  return check_launch("spline_band_kernel");
+}
+
 bool mmse_factored_usable(int np, int np_pad) { return np % 4 == 0 && np_pad % 16 == 0 && !getenv("OFDM_MMSE_NO_MFMA") && !getenv("OFDM_MMSE_DENSE"); }
 
 int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* y, void* v,
@@ -313,11 +325,10 @@ int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32
   else if (G >= 4) launch(mmse_apply_mfma_kernel<4>, 4);
   else if (G >= 2) launch(mmse_apply_mfma_kernel<2>, 2);
   else launch(mmse_apply_mfma_kernel<1>, 1);
-  const dim3 g2((unsigned)((n_carrier + SB_ROWS - 1) / SB_ROWS), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
-  const size_t lds = sizeof(cx<float>) * (size_t)span * SB_VS + sizeof(float) * (size_t)bw * SB_ROWS;
-  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(SB_ROWS), lds, st, sb_w, sb_c0, bw, span, (const cx<float>*)v, (cx<float>*)hout,
-                     n_carrier, np, n_frames);
-  return check_launch("mmse factored stage");
+  OFDM_TRY(check_launch("mmse_apply_mfma_kernel"));
+  const int rc = spline_band_run(sb_w, sb_c0, bw, span, v, hout, np, n_carrier, n_frames);
+  OFDM_ARG(rc <= 0, "rx_chain_task5 (MMSE mode): the spline band does not fit the LDS");
+  return rc;
 }
 
 template <typename T>

@@ -1085,6 +1085,15 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
     std::vector<T> Wt(W.begin(), W.end());
     OFDM_HIP(hipMalloc(&pl->d_t4_w, sizeof(T) * Wt.size()));
     OFDM_HIP(hipMemcpy(pl->d_t4_w, Wt.data(), sizeof(T) * Wt.size(), hipMemcpyHostToDevice));
+    if (!f64) {                                      // fp32: the operator's band (weights below 1e-10 of a row's largest dropped)
+      std::vector<float> bw_w;
+      std::vector<int32_t> bw_c0;
+      mmse_band_spline(W, nc, np, bw_w, bw_c0, pl->t4_bw, pl->t4_span);
+      OFDM_HIP(hipMalloc(&pl->d_t4_bw, sizeof(float) * bw_w.size()));
+      OFDM_HIP(hipMemcpy(pl->d_t4_bw, bw_w.data(), sizeof(float) * bw_w.size(), hipMemcpyHostToDevice));
+      OFDM_HIP(hipMalloc(&pl->d_t4_bc0, sizeof(int32_t) * bw_c0.size()));
+      OFDM_HIP(hipMemcpy(pl->d_t4_bc0, bw_c0.data(), sizeof(int32_t) * bw_c0.size(), hipMemcpyHostToDevice));
+    }
   }
   const void *dtx = pl->d_t4_tx, *dW = pl->d_t4_w;
   if (sync) OFDM_ARG(np >= 2, "rx_chain_task4: fine_sync needs at least two pilot carriers");
@@ -1115,8 +1124,13 @@ static int task4_run(ofdm_rx_plan* pl, const void* drx, int64_t F, int time_desy
       hipLaunchKernelGGL(t4_mean_pilots_kernel<T>, dim3(cdiv_u(np, 128), (unsigned)F), dim3(128), 0, s,
                          direct ? (const cx<T>*)dXp : (const cx<T>*)dX, (const cx<T>*)dtx, (const int32_t*)pl->d_pc0, (cx<T>*)dhp, N, np, S,
                          lazy_rot, time_desync, freq_desync, direct ? 1 : 0);
-    hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), sizeof(cx<T>) * np * T4_FT, s, (const T*)dW,
-                       (const cx<T>*)dhp, (cx<T>*)dH, nc, np, F);
+    int band = 1;                                    // fp32: banded product (0.084 -> 0.04 ms per 4096 frames at C3), else the dense tile product
+    if (!f64 && pl->d_t4_bw && !getenv("OFDM_T4_DENSE_SPLINE"))
+      band = spline_band_run((const float*)pl->d_t4_bw, (const int32_t*)pl->d_t4_bc0, pl->t4_bw, pl->t4_span, dhp, dH, np, nc, F);
+    OFDM_TRY(band);
+    if (band == 1)
+      hipLaunchKernelGGL(t4_apply_operator_kernel<T>, dim3(cdiv_u(nc, 128), cdiv_u(F, T4_FT)), dim3(128), sizeof(cx<T>) * np * T4_FT, s, (const T*)dW,
+                         (const cx<T>*)dhp, (cx<T>*)dH, nc, np, F);
   } else {
     hipLaunchKernelGGL(t4_fill_ones_kernel<T>, dim3(256), dim3(256), 0, s, (cx<T>*)dH, (int64_t)nc * F);
   }

@@ -37,6 +37,8 @@ struct ofdm_rx_plan {
   void* d_dict = nullptr;  // constellation table in the plan's precision (ofdm_tx_frames)
   void* d_t4_tx = nullptr; // ofdm_rx_chain_task4: pilot matrix [np x n_symb] and spline operator [n_carrier x np] (built once)
   void* d_t4_w = nullptr;
+  void *d_t4_bw = nullptr, *d_t4_bc0 = nullptr;      // fp32: the same operator cut to its band (spline_band_kernel)
+  int t4_bw = 0, t4_span = 0;
   void* ws_t4 = nullptr;   // ofdm_rx_chain_task4: arena for its per-batch intermediates
   size_t ws_t4_bytes = 0;
   void* ws_raw = nullptr;  // raw packed decisions of a batch when the DeScrambler runs as a pass of its own (descr_pass_kernel)
