@@ -78,9 +78,14 @@ bool modem_wave_supported(int nfft) {
 }
 
 // device pointers; modulate = false: OFDM_demodulator, true: OFDM_modulator
+bool modem_run_supported(int nfft, int t_guard, bool f64, bool mod);                             // ofdm_modem_run.hip
+int modem_run_launch(const void* in, void* out, const void* tw, int nfft, int64_t n_symb, int t_guard, bool mod);
+
 int modem_wave_run(const void* in, void* out, int nfft, int64_t n_symb, int t_guard, bool f64, bool modulate) {
   const void* tw = nullptr;
   OFDM_TRY(get_twiddles(nfft, f64, &tw));
+  // fp32, Nfft 1024 / 2048: one wavefront per run of symbols (no workgroup barrier, whole-line stores)
+  if (modem_run_supported(nfft, t_guard, f64, modulate)) return modem_run_launch(in, out, tw, nfft, n_symb, t_guard, modulate);
 #define MW_CALL(NWV)                                                                                             \
   if (f64) return modulate ? modem_wave_launch<double, NWV, true>(in, out, tw, n_symb, t_guard)                  \
                            : modem_wave_launch<double, NWV, false>(in, out, tw, n_symb, t_guard);                \

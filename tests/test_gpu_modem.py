@@ -129,3 +129,32 @@ def test_equalize_signal(ofdm, oracle, dt, tol):
     assert np.all(got[200:] == 0)
     with pytest.raises(ofdm.OfdmError):
         ofdm.equalize_signal(x, h[:100], 200)
+
+
+@pytest.mark.parametrize("nfft", [1024, 2048])
+def test_wave_per_run_modem_fp32(ofdm, oracle, monkeypatch, nfft):
+    """modem_run_kernel (fp32, Nfft 1024 / 2048: one wavefront per run of symbols, whole-line stores, CP rows stored from the
+    same registers) for runs of 1, 3 and 64 symbols over a ragged symbol count, guards of 0, 2, Nfft/8 and Nfft - 2, against the
+    oracle and bit for bit against itself across run lengths; an odd guard takes the cooperative modulator (same results)."""
+    rng = np.random.default_rng(nfft)
+    ns = 83
+    for tg in (0, 2, nfft // 8, nfft - 2, 7):
+        x = crandn(rng, nfft, ns).astype(np.complex64)
+        y = crandn(rng, nfft + tg, ns).astype(np.complex64)
+        want_m = oracle.OFDM_modulator(x.astype(np.complex128), tg)
+        want_d = oracle.OFDM_demodulator(y.astype(np.complex128), tg)
+        first = None
+        for spc in ("1", "3", "64"):
+            monkeypatch.setenv("OFDM_MODEM_RUN_SPC", spc)
+            gm, gd = ofdm.OFDM_modulator(x, tg), ofdm.OFDM_demodulator(y, tg)
+            assert rel_l2(gm, want_m) <= 1e-6 * np.log2(nfft) and rel_l2(gd, want_d) <= 1e-6 * np.log2(nfft)
+            assert np.array_equal(gm[:tg], gm[nfft:])                      # CP rows are bitwise copies (OFDM_modulator.m:8-9)
+            if first is None:
+                first = (gm.copy(), gd.copy())
+            else:
+                assert np.array_equal(gm, first[0]) and np.array_equal(gd, first[1])
+        monkeypatch.delenv("OFDM_MODEM_RUN_SPC")
+        monkeypatch.setenv("OFDM_MODEM_NO_RUN", "1")                        # the cooperative kernels on the same data
+        gm2, gd2 = ofdm.OFDM_modulator(x, tg), ofdm.OFDM_demodulator(y, tg)
+        monkeypatch.delenv("OFDM_MODEM_NO_RUN")
+        assert rel_l2(first[0], gm2) < 2e-6 and rel_l2(first[1], gd2) < 2e-6

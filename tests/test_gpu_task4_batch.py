@@ -176,32 +176,36 @@ def test_batch_acf_prefix_and_full_scan(ofdm, monkeypatch, full_acf):
     assert int(out["TgPosition"][1]) == 65 and int(out["TgPosition"][2]) > 4096
 
 
-def test_batch_against_oracle_replay_nfft2048_many_draws(ofdm, oracle):
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_batch_against_oracle_replay_nfft2048_many_draws(ofdm, oracle, precision):
     """BASELINE config 3 geometry (Nfft 2048, N_carrier 800, 64-QAM) with TEN frames, each its own STO / CFO / noise draw,
     replayed frame by frame on the oracle (T4/Main_model_Task_4.m:278-347): TgPosition, FreqOffset, IFO and status for
     every frame, H and bits for every frame the reference decodes.  Draws where remove_IFO.m:6-8 finds no line above
     0.77 (`inds(1)` errors in MATLAB) must come back with status -1 -- one frame is attenuated so that this path is
     exercised whatever the draws do; most other draws lock onto a leakage line (the reference's fragile 0.77 rule), which
-    the batch must reproduce line for line as well."""
+    the batch must reproduce line for line as well.  fp32 = the wave-per-symbol-run demodulator, the one-launch IFO search and the
+    fused estimate stage (ofdm_t4_wave.hip) against the float64 oracle: TgPosition / IFO / status exact, FreqOffset to 1e-6, H to
+    2e-4, decisions that differ only where the oracle's equalised point sits on a decision boundary (tests/flip_audit.py)."""
     from ofdm_course_amd import frames as fr
     cfg_kw = dict(Nfft=2048, N_carrier=800, N_symb=8, const="64QAM")
     nfr = 10
-    d = _frames(ofdm, cfg_kw, nfr, "fp64", seed=21)
+    d = _frames(ofdm, cfg_kw, nfr, precision, seed=21)
+    f64 = precision == "fp64"
     d["rx"][:, 7] *= 1e-3                                  # no spectral line reaches 0.77: remove_IFO's index error
     Tg, N = d["Tg"], 2048
     K = int(np.ceil(800 / 6))
-    plan = ofdm.RxPlan(N, Tg, 8, 800, d["pil"], d["dat"], d["col"], K, 3, "64QAM", precision="fp64")
+    plan = ofdm.RxPlan(N, Tg, 8, 800, d["pil"], d["dat"], d["col"], K, 3, "64QAM", precision=precision)
     out = ofdm.rx_chain_task4(plan, d["rx"], 1, 1, 1, want_h=True)
     got_bits = fr.unpack_bits(np.asarray(out["bits"]), d["bits"].shape[1])
     decoded = failed = 0
     import warnings
     for f in range(nfr):
-        y = d["rx"][:, f]
+        y = d["rx"][:, f].astype(np.complex128)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             _, pos, fo, ok = oracle.AutoCorrFunction(y, Tg, N)
         assert int(out["TgPosition"][f]) == pos, f
-        assert abs(float(out["FreqOffset"][f]) - fo) < 1e-9 or (np.isnan(fo) and np.isnan(float(out["FreqOffset"][f])))
+        assert abs(float(out["FreqOffset"][f]) - fo) < (1e-9 if f64 else 1e-6) or (np.isnan(fo) and np.isnan(float(out["FreqOffset"][f])))
         y = oracle.add_STO(oracle.add_STO(y, pos), -(N + Tg))
         y = oracle.add_CFO(y, -fo, N)
         try:
@@ -218,10 +222,15 @@ def test_batch_against_oracle_replay_nfft2048_many_draws(ofdm, oracle):
         if not np.all(np.isfinite(H[:800])):
             assert np.array_equal(np.isnan(np.asarray(out["H"])[:, f]), np.isnan(H[:800]))
             continue
-        assert rel_l2(np.asarray(out["H"])[:, f], H[:800]) < 1e-8, f
-        want = np.asarray(oracle.demapping(0, oracle.get_payload(oracle.equalize_signal(X, H, 800), d["dat"]).ravel(order="F"),
-                                           "64QAM")).ravel()
-        assert np.count_nonzero(got_bits[f] != want) <= 2, f
+        assert rel_l2(np.asarray(out["H"])[:, f], H[:800]) < (1e-8 if f64 else 2e-4), f
+        iq = oracle.get_payload(oracle.equalize_signal(X, H, 800), d["dat"]).ravel(order="F")
+        want = np.asarray(oracle.demapping(0, iq, "64QAM")).ravel()
+        if f64:
+            assert np.count_nonzero(got_bits[f] != want) <= 2, f
+        else:
+            from flip_audit import decision_flip_audit
+            # the fp32 chain's H differs from the oracle's by ~1e-5: a decision may move where the point is within that of a boundary
+            decision_flip_audit(oracle, got_bits[f], want, iq, "64QAM", band=2e-3, what=f"T4 fp32 frame {f}")
         decoded += 1
     assert failed >= 1 and decoded >= 3, (failed, decoded)
 

@@ -1,14 +1,13 @@
-# Round-3 evidence in ONE gpurun call (same box): the driver-contract bench line (M fp32 + f64 leg + C2..C5), kernel trace stats of
-# every leg, PMC passes + HBM traffic of the metric chain, counters of the new C3 / C4 / C5 kernels.
+# Round-3 evidence in ONE gpurun call (same box): the driver-contract bench line (M fp32 + f64 leg + C2..C5) FIRST, on the fresh box
+# (the same kernels read 10 % slower after the six PMC passes have kept the part flat out for a minute: 0.87 against 0.77 ms for the
+# symbol kernel), then kernel trace stats of every leg, counters of the new C3 / C4 / C5 kernels, PMC passes + HBM traffic of the
+# metric chain last.
 # usage (on the GPU box): bash tools/evidence3.sh   -> gpurun_out/evidence3/ ; copy the summaries into profiles/round3/
 set -o pipefail
 out=gpurun_out/evidence3; mkdir -p $out
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 step() { echo "== $1" >> $out/progress.txt; date >> $out/progress.txt; }
-step pmc
-bash tools/pmc.sh $out/pmc > $out/final_pmc_summary.txt 2>&1 || { echo "pmc failed"; exit 1; }
-python tools/pmc_traffic.py $out/pmc > $out/traffic.json && mkdir -p profiles/round3 && cp $out/traffic.json profiles/round3/traffic.json
 step bench
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $out/bench_20steps.json 2> $out/bench.err
 timeout -k 10 600 python bench.py > $out/final_bench.json 2>> $out/bench.err || { echo "bench failed"; exit 1; }
@@ -31,6 +30,9 @@ step c5_split
 OFDM_SPLIT_NO_COOP=1 timeout -k 10 300 python tools/c5_run.py 3072 20 > $out/c5_split_form.txt 2>&1
 step sweep
 timeout -k 10 300 python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 2 --frames-per-tile 64 --json $out/sweep_c5.json > /dev/null 2>&1
+step pmc
+bash tools/pmc.sh $out/pmc > $out/final_pmc_summary.txt 2>&1 || echo "pmc failed"
+python tools/pmc_traffic.py $out/pmc > $out/traffic.json
 step clock
 if [ -f ofdm-course_amd/libofdm_mi355x_diag.so ]; then bash tools/clock_probe.sh $out/clock > $out/clock_probe.txt 2>&1; fi
 step ubench
