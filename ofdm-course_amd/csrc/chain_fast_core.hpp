@@ -611,7 +611,7 @@ struct FastPlanView {
   int* fused_out;          // set to 1 when kernels 1+2 ran as one launch (then ev[2] is not recorded)
   const void* d_wt;        // MMSE mode: W^T [np][m_pad] in the plan's precision, else nullptr
   int m_pad;
-  const void* d_mt;        // fp32 MMSE mode, factored form: M^T [np][np_pad], the banded spline (w [bw][nc], c0 [nc]); else nullptr
+  const void* d_mt;        // fp32 MMSE mode, factored form: M^T [np][np_pad], the banded spline per quad of rows (w [bw][nq][4], c0 [nq]); else nullptr
   int np_pad, sb_bw, sb_span;
   const float* d_sb_w;
   const int32_t* d_sb_c0;

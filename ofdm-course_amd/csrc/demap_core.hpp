@@ -128,31 +128,26 @@ __device__ __forceinline__ int demap_square_lut(const DemapTable<T>& t, const T*
   return (ci << BA) | cq;
 }
 
-// Throughput-mode slicer (fp32 chain only): the level rank from the distance to the CENTRE threshold -- which is compared
-// exactly, so the reference's tie rule holds at 0 (blanked carriers) -- by one multiply and one truncation: the other thresholds
-// are k * d from the centre up to rounding, so a decision can differ from demap_square only for a coordinate within a few ulp
-// (~1e-7 relative) of a threshold -- inside the 1e-4 band SURVEY.md section 8c allows the fp32 mode ("decisions may differ
-// only for points within 1e-4 of a decision boundary").  7 instead of 14 VALU operations per axis at 64-QAM.  NaN keeps
-// demap_square's outcome (rank 0 on I, L - 1 on Q).
+// Throughput-mode slicer (fp32 chain only): the level rank from the signed distance to the CENTRE threshold in units of the level
+// spacing.  On I the rank is the number of thresholds strictly below x = HALF - 1 + ceil((x - mid) / d); on Q the kernel needs
+// the reversed rank L - 1 - (thresholds strictly below y) = HALF + floor((mid - y) / d).  Both hold the reference's tie rule at
+// the centre exactly (x == mid: rank HALF - 1; the difference x - mid is exact there), so blanked carriers decide as in
+// demap_square; the other thresholds are k * d from the centre up to rounding, so a decision can differ from demap_square only
+// for a coordinate within a few ulp (~1e-7 relative) of a threshold -- inside the 1e-4 band SURVEY.md section 8c allows the fp32
+// mode.  The clamp is done on the float (v_max / v_min return the non-NaN operand: NaN lands on rank 0 on I and on reversed
+// rank 0 = rank L - 1 on Q, demap_square's outcome).  6 VALU operations per axis (sub, mul, max, min, ceil / floor, cvt + the
+// add folded into the Gray step) -- the first arithmetic form (|.|, truncate, min, select by sign, two NaN selects) took 10,
+// the threshold count 14 at 64-QAM.
 template <int BA>
 __device__ __forceinline__ int demap_square_arith(const DemapTable<float>& t, cx<float> z) {
   constexpr int L = 1 << BA, HALF = L / 2;
-  int g[2];
-#pragma unroll
-  for (int ax = 0; ax < 2; ++ax) {
-    const float x = ax == 0 ? z.x : z.y;
-    const float mid = ax == 0 ? t.thr_i[HALF - 1] : t.thr_q[HALF - 1];
-    const float a = x - mid;
-    int f = (int)(fabsf(a) * t.inv_d);                              // thresholds at mid +- k d
-    f = f > HALF - 1 ? HALF - 1 : f;
-    int l = x > mid ? HALF + f : HALF - 1 - f;
-    if (x != x) l = 0;
-    g[ax] = l;
-  }
-  int li = g[0], lq = g[1];
-  if (z.y != z.y) lq = L - 1;
+  float ui = (z.x - t.thr_i[HALF - 1]) * t.inv_d;
+  float uq = (t.thr_q[HALF - 1] - z.y) * t.inv_d;
+  ui = fminf(fmaxf(ui, -(float)(HALF - 1)), (float)HALF);
+  uq = fminf(fmaxf(uq, -(float)HALF), (float)(HALF - 1));
+  const int li = (HALF - 1) + (int)ceilf(ui);
+  const int lr = HALF + (int)floorf(uq);
   const int ci = li ^ (li >> 1);
-  const int lr = (L - 1) - lq;
   const int cq = lr ^ (lr >> 1);
   return (ci << BA) | cq;
 }

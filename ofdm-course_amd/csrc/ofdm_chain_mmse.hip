@@ -217,55 +217,103 @@ __global__ __launch_bounds__(256) void mmse_apply_valu_kernel(const cx<T>* __res
 // weight of a not-a-knot spline falls by (2 - sqrt 3) per knot, so each row keeps the `bw` columns around its interval whose
 // weights reach 1e-10 of the row's largest (33 columns at 256 knots) -- below half an fp32 ulp of the result.
 //   (1) v[f][:] = M * Y[f][:]     mmse_apply_mfma_kernel on M^T [np][np_pad]          (8 np^2 flop per frame)
-//   (2) H[f][m] = sum_t w[t][m] v[f][c0[m] + t]     spline_band_kernel: v tile in LDS, weights t-major
+//   (2) H[f][m] = sum_t w[t][m] v[f][c0[m] + t]     spline_band_kernel: v tile and weights in LDS, a quad of rows x 8 frames per thread
 // fp64 plans keep the dense operator on VALU (parity mode: unchanged results).
 // ---------------------------------------------------------------------------------------------
-constexpr int SB_FT = 32;                                     // frames per workgroup
-constexpr int SB_ROWS = 128;                                  // rows (carriers) per workgroup = threads
-constexpr int SB_VS = SB_FT + 2;                              // v tile row stride: 272 B, so the 16 windows a wavefront's rows start in
-                                                              // read 16 different 16-byte bank groups (256 B apart they were a 16-way conflict: 147 us)
-// One workgroup = SB_ROWS carriers x SB_FT frames.  The rows of a workgroup use the columns c_lo .. c_lo + span - 1 only (their
-// bands overlap: 128 carriers at comb 4 span 32 knots + the band width), so the v tile in LDS is [span][SB_FT]; the rows' weights
-// [bw][SB_ROWS] sit in LDS as well -- the inner loop touches LDS only.  (First form: 8 frames per workgroup, the weight of every
-// step loaded from L2 inside the loop -- 33 dependent L2 latencies per thread: 74 us per 8192 frames.)
-__global__ __launch_bounds__(SB_ROWS) void spline_band_kernel(const float* __restrict__ w, const int32_t* __restrict__ c0, int bw, int span,
-                                                              const cx<float>* __restrict__ v, cx<float>* __restrict__ hout, int nc,
-                                                              int np, int64_t n_frames) {
+constexpr int SB_FT = 32;                                     // frames per workgroup (8 per wavefront)
+constexpr int SB_QUADS = 64;                                  // quads of rows per workgroup = lanes: 256 carriers
+constexpr int SB_VS = SB_FT + 2;                              // v tile row stride: 272 B, so the windows a wavefront's lanes start in spread over
+                                                              // the 16-byte bank groups (256 B apart they were a 16-way conflict: 147 us)
+// One thread = one QUAD of neighbouring rows (4q .. 4q+3: at comb 4 one knot interval, their windows coincide) x 8 frames; one
+// workgroup = 64 quads x 32 frames (wavefront w takes frames 8w .. 8w+7).  Per tap a thread reads 16 B of weights and 64 B of v
+// from LDS for 64 FMAs (1.25 B per FMA).  The first form -- one row x 32 frames per thread, 4 B of LDS per FMA -- was bound by
+// the LDS: 67 us per 8192 frames of C4.  The weights of a row outside its own window [c0, c0 + bw) are zero, fmaf(0, x, acc) == acc:
+// every row sums the same products in the same order as before.
+__global__ __launch_bounds__(256) void spline_band_kernel(const float4* __restrict__ w4, const int32_t* __restrict__ c4, int bw, int span,
+                                                          const cx<float>* __restrict__ v, cx<float>* __restrict__ hout, int nc,
+                                                          int np, int64_t n_frames) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
   cx<float>* const vs = (cx<float>*)sb_smem;                  // [span][SB_VS]
-  float* const ws = (float*)(vs + (size_t)span * SB_VS);      // [bw][SB_ROWS]
-  const int m0 = blockIdx.x * SB_ROWS, m = m0 + threadIdx.x;
+  float4* const ws = (float4*)(vs + (size_t)span * SB_VS);    // [bw][SB_QUADS]
+  const int nq = (nc + 3) >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * SB_QUADS, q = q0 + lane;
   const int64_t f0 = (int64_t)blockIdx.y * SB_FT;
-  const int c_lo = c0[m0];                                    // c0 is non-decreasing in m
-  for (int i = threadIdx.x; i < span * SB_FT; i += SB_ROWS) {
-    const int f = i / span, j = i - f * span;                 // coalesced over the pilots of one frame
-    const bool ok = f0 + f < n_frames && c_lo + j < np;
-    vs[j * SB_VS + f] = ok ? v[(f0 + f) * np + c_lo + j] : mk<float>(0, 0);
+  const int c_lo = c4[q0];                                    // c4 is non-decreasing in q
+  // every load of the two tiles is in flight before the first LDS write (a loop of dependent round trips was 3/4 of the kernel's time):
+  // wavefront w takes frames w, w + 4, ... (two coalesced runs of 64 pilots each) and the taps w, w + 4, ...
+  for (int jb = 0; jb < span; jb += 128) {
+    cx<float> tv[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int f = wave + 4 * k, j = jb + lane + 64 * h;
+        const bool ok = j < span && f0 + f < n_frames && c_lo + j < np;
+        tv[k][h] = ok ? v[(f0 + f) * np + c_lo + j] : mk<float>(0, 0);
+      }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = jb + lane + 64 * h;
+        if (j < span) vs[j * SB_VS + wave + 4 * k] = tv[k][h];
+      }
   }
-  for (int t = 0; t < bw; ++t) ws[t * SB_ROWS + threadIdx.x] = m < nc ? w[(size_t)t * nc + m] : 0.f;
-  __syncthreads();
-  if (m >= nc) return;
-  const int j0 = c0[m] - c_lo;
-  cx<float> acc[SB_FT];
+  for (int tb = 0; tb < bw; tb += 48) {
+    float4 tw[12];
 #pragma unroll
-  for (int f = 0; f < SB_FT; ++f) acc[f] = mk<float>(0, 0);
-  for (int t = 0; t < bw; ++t) {
-    const float wt = ws[t * SB_ROWS + threadIdx.x];
-    const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t) * SB_VS);
+    for (int k = 0; k < 12; ++k) {
+      const int t = tb + wave + 4 * k;
+      tw[k] = t < bw && q < nq ? w4[(size_t)t * nq + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-    for (int f2 = 0; f2 < SB_FT / 2; ++f2) {
-      const float4 x = row[f2];
-      acc[2 * f2].x = fmaf(wt, x.x, acc[2 * f2].x);     acc[2 * f2].y = fmaf(wt, x.y, acc[2 * f2].y);
-      acc[2 * f2 + 1].x = fmaf(wt, x.z, acc[2 * f2 + 1].x); acc[2 * f2 + 1].y = fmaf(wt, x.w, acc[2 * f2 + 1].y);
+    for (int k = 0; k < 12; ++k) {
+      const int t = tb + wave + 4 * k;
+      if (t < bw) ws[t * SB_QUADS + lane] = tw[k];
     }
   }
+  __syncthreads();
+  if (q >= nq) return;
+  const int j0 = c4[q] - c_lo;
+  cx<float> acc[4][8];
 #pragma unroll
-  for (int f = 0; f < SB_FT; ++f)
-    if (f0 + f < n_frames) hout[(f0 + f) * nc + m] = acc[f];
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[r][f] = mk<float>(0, 0);
+  for (int t = 0; t < bw; ++t) {
+    const float4 w = ws[t * SB_QUADS + lane];
+    const float wr[4] = {w.x, w.y, w.z, w.w};
+    const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t) * SB_VS + 8 * wave);
+#pragma unroll
+    for (int f2 = 0; f2 < 4; ++f2) {
+      const float4 x = row[f2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[r][2 * f2].x = fmaf(wr[r], x.x, acc[r][2 * f2].x);         acc[r][2 * f2].y = fmaf(wr[r], x.y, acc[r][2 * f2].y);
+        acc[r][2 * f2 + 1].x = fmaf(wr[r], x.z, acc[r][2 * f2 + 1].x); acc[r][2 * f2 + 1].y = fmaf(wr[r], x.w, acc[r][2 * f2 + 1].y);
+      }
+    }
+  }
+  const bool wide = (nc & 1) == 0 && 4 * q + 3 < nc;          // 16-byte stores need an even row length
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int64_t fr = f0 + 8 * wave + f;
+    if (fr >= n_frames) break;
+    cx<float>* o = hout + fr * nc + 4 * q;
+    if (wide) {
+      reinterpret_cast<float4*>(o)[0] = make_float4(acc[0][f].x, acc[0][f].y, acc[1][f].x, acc[1][f].y);
+      reinterpret_cast<float4*>(o)[1] = make_float4(acc[2][f].x, acc[2][f].y, acc[3][f].x, acc[3][f].y);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < nc) o[r] = acc[r][f];
+    }
+  }
 }
 
-// rows of the spline operator cut to a common band width: w [bw][nc] (t-major), c0 [nc]
-// span = the largest number of columns the SB_ROWS rows of one workgroup of spline_band_kernel touch
+// rows of the spline operator cut to their band, per quad of rows: w [bw][nq][4] (t-major), c0 [nq] = first column of the quad's
+// window, nq = ceil(nc / 4).  span = the largest number of columns the 64 quads of one workgroup of spline_band_kernel touch
 void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw, int& span) {
   // columns [lo, hi] of a row that reach 1e-10 of its largest weight (a row AT a knot is a unit vector: lo = hi = the knot)
   std::vector<int> lo(nc), hi(nc);
@@ -278,33 +326,47 @@ void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vecto
     if (b < 0) { a = 0; b = 0; }
     lo[m] = a; hi[m] = b;
   }
-  // first column of a row's window = the smallest lo of this and every later row: non-decreasing in m (the kernel takes a
-  // workgroup's column range from its first and last row) and never to the right of the row's own first column
-  c0.resize(nc);
+  // a ROW's window: first column = the smallest lo of this and every later row (non-decreasing in m, never to the right of the
+  // row's own first column), width rbw = the largest hi - first + 1 of any row
+  std::vector<int> r0(nc);
   int smin = np;
-  for (int m = nc - 1; m >= 0; --m) { smin = std::min(smin, lo[m]); c0[m] = smin; }
-  bw = 1;
-  for (int m = 0; m < nc; ++m) bw = std::max(bw, hi[m] - c0[m] + 1);
+  for (int m = nc - 1; m >= 0; --m) { smin = std::min(smin, lo[m]); r0[m] = smin; }
+  int rbw = 1;
+  for (int m = 0; m < nc; ++m) rbw = std::max(rbw, hi[m] - r0[m] + 1);
+  rbw = std::min(np, rbw);
+  for (int m = 0; m < nc; ++m) r0[m] = std::max(0, std::min(r0[m], np - rbw));
+  // a QUAD's window: from its first row's first column to its last row's last column
+  const int nq = (nc + 3) / 4;
+  bw = rbw;
+  for (int q = 0; q < nq; ++q) bw = std::max(bw, r0[std::min(nc - 1, 4 * q + 3)] + rbw - r0[4 * q]);
   bw = std::min(np, bw);
-  for (int m = 0; m < nc; ++m) c0[m] = std::max(0, std::min(c0[m], np - bw));
-  w.assign((size_t)bw * nc, 0.f);
-  for (int m = 0; m < nc; ++m)
-    for (int t = 0; t < bw; ++t) w[(size_t)t * nc + m] = (float)sop[m + (size_t)(c0[m] + t) * nc];
+  c0.resize(nq);
+  w.assign((size_t)bw * nq * 4, 0.f);
+  for (int q = 0; q < nq; ++q) {
+    const int base = std::max(0, std::min(r0[4 * q], np - bw));
+    c0[q] = base;
+    for (int t = 0; t < bw; ++t)
+      for (int r = 0; r < 4 && 4 * q + r < nc; ++r) {
+        const int m = 4 * q + r, col = base + t;
+        if (col >= r0[m] && col < r0[m] + rbw) w[((size_t)t * nq + q) * 4 + r] = (float)sop[m + (size_t)col * nc];
+      }
+  }
   span = bw;
-  for (int m0 = 0; m0 < nc; m0 += 128) {
-    const int last = std::min(nc, m0 + 128) - 1;
-    span = std::max(span, c0[last] + bw - c0[m0]);
+  for (int q0 = 0; q0 < nq; q0 += SB_QUADS) {
+    const int last = std::min(nq, q0 + SB_QUADS) - 1;
+    span = std::max(span, c0[last] + bw - c0[q0]);
   }
 }
 
 // the banded product on its own (the Task-4 receiver's estimate_channel.m:8 on fp32 plans): H[f][m] = sum_t w[t][m] v[f][c0[m] + t]
 int spline_band_run(const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* v, void* hout, int np, int n_carrier,
                     int64_t n_frames) {
-  const dim3 g2((unsigned)((n_carrier + SB_ROWS - 1) / SB_ROWS), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
-  const size_t lds = sizeof(cx<float>) * (size_t)span * SB_VS + sizeof(float) * (size_t)bw * SB_ROWS;
+  const int nq = (n_carrier + 3) / 4;
+  const dim3 g2((unsigned)((nq + SB_QUADS - 1) / SB_QUADS), (unsigned)((n_frames + SB_FT - 1) / SB_FT));
+  const size_t lds = sizeof(cx<float>) * (size_t)span * SB_VS + sizeof(float4) * (size_t)bw * SB_QUADS;
   if (lds > 150 * 1024) return 1;                              // not taken: the caller keeps its dense product
   (void)hipFuncSetAttribute((const void*)spline_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(SB_ROWS), lds, ctx().stream, sb_w, sb_c0, bw, span, (const cx<float>*)v,
+  hipLaunchKernelGGL(spline_band_kernel, g2, dim3(256), lds, ctx().stream, (const float4*)sb_w, sb_c0, bw, span, (const cx<float>*)v,
                      (cx<float>*)hout, n_carrier, np, n_frames);
   return check_launch("spline_band_kernel");
 }
