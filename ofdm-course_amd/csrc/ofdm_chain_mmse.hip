@@ -108,17 +108,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // G = frame groups of 8 per wavefront: 8 (32 rows x 64 frames) for the tall dense operator, fewer for the small [Np x Np]
 // factor, whose grid would otherwise leave one workgroup per CU
+// the accumulation of one wavefront's tile: rows m0 .. m0 + 31 (two 16-row tiles) x frames f0 .. f0 + 8 G - 1
 template <int G>
-__global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* __restrict__ wt, const cx<float>* __restrict__ y,
-                                                              cx<float>* __restrict__ hout, int np, int m_pad, int n_carrier,
-                                                              int64_t n_frames) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void mmse_tile_mfma(const cx<float>* __restrict__ wt, const cx<float>* __restrict__ y, int np, int m_pad, int m0,
+                                               bool two, int64_t f0, int64_t n_frames, int lane, f32x4 (&acc)[2][G]) {
   const int i16 = lane & 15, q = lane >> 4, fsub = i16 >> 1, cim = i16 & 1;
-  const int m0 = (blockIdx.y * 4 + wave) * 32;
-  if (m0 >= m_pad) return;                                   // wavefront-uniform
-  const bool two = m0 + 16 < m_pad;                          // wavefront-uniform: second carrier tile exists
-  const int64_t f0 = (int64_t)blockIdx.x * (8 * G);
-  f32x4 acc[2][G];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -172,6 +166,20 @@ __global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* _
 #pragma unroll
     for (int g = 0; g < G; ++g) b[g] = bn[g];
   }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void mmse_apply_mfma_kernel(const cx<float>* __restrict__ wt, const cx<float>* __restrict__ y,
+                                                              cx<float>* __restrict__ hout, int np, int m_pad, int n_carrier,
+                                                              int64_t n_frames) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i16 = lane & 15, q = lane >> 4, fsub = i16 >> 1, cim = i16 & 1;
+  const int m0 = (blockIdx.y * 4 + wave) * 32;
+  if (m0 >= m_pad) return;                                   // wavefront-uniform
+  const bool two = m0 + 16 < m_pad;                          // wavefront-uniform: second carrier tile exists
+  const int64_t f0 = (int64_t)blockIdx.x * (8 * G);
+  f32x4 acc[2][G];
+  mmse_tile_mfma<G>(wt, y, np, m_pad, m0, two, f0, n_frames, lane, acc);
   // C: lane holds rows 4*(lane>>4)+r of column lane&15
   float* ho = reinterpret_cast<float*>(hout);
 #pragma unroll
@@ -312,6 +320,95 @@ __global__ __launch_bounds__(256) void spline_band_kernel(const float4* __restri
   }
 }
 
+// Both factors in ONE launch (Np <= 256): a 512-thread workgroup owns 32 frames.  Phase 1: wavefront w accumulates rows 32 w .. 32 w + 31
+// of v = M * Y for the 32 frames (mmse_tile_mfma<4>: the eight wavefronts read the same Y rows -- L1 hits -- and M^T once per
+// workgroup) and writes them to the v tile in LDS [Np][SB_VS].  Phase 2: the banded spline from that tile, a quad of rows x 8 frames
+// per thread as in spline_band_kernel, the weights straight from L2 (one batch of four taps ahead).  Against the two launches:
+// no v round trip, no tile / weight load phase, 147 MB instead of 268 MB through the L2 -> L1 path.  Bit-identical results.
+template <int FT>
+__global__ __launch_bounds__(512) void mmse_fused_kernel(const cx<float>* __restrict__ mt, const cx<float>* __restrict__ y,
+                                                         const float4* __restrict__ w4, const int32_t* __restrict__ c4, int bw,
+                                                         cx<float>* __restrict__ hout, int np, int np_pad, int nc, int64_t n_frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+  constexpr int G = FT / 8, VS = FT + 2;
+  cx<float>* const vs = (cx<float>*)mf_smem;                  // [np_pad][VS]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t f0 = (int64_t)blockIdx.x * FT;
+  {
+    const int m0 = wave * 32;
+    if (m0 < np_pad) {                                        // wavefront-uniform
+      const int i16 = lane & 15, q = lane >> 4, fsub = i16 >> 1, cim = i16 & 1;
+      const bool two = m0 + 16 < np_pad;
+      f32x4 acc[2][G];
+      mmse_tile_mfma<G>(mt, y, np, np_pad, m0, two, f0, n_frames, lane, acc);
+      float* vf = reinterpret_cast<float*>(vs);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vf[2 * ((m0 + 16 * t + 4 * q + r) * VS + 8 * g + fsub) + cim] = acc[t][g][r];
+      }
+    }
+  }
+  __syncthreads();
+  const int nq = (nc + 3) >> 2;
+  const int n_task = ((nq + 63) >> 6) * G;                    // (64 quads) x (8 frames)
+  for (int task = wave; task < n_task; task += 8) {
+    const int q = (task / G) * 64 + lane, fg = task % G;
+    const bool qok = q < nq;
+    const int qc = qok ? q : nq - 1;
+    const int j0 = c4[qc];
+    cx<float> acc[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc[r][f] = mk<float>(0, 0);
+    float4 wn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wn[k] = k < bw ? w4[(size_t)k * nq + qc] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = 0; t0 < bw; t0 += 4) {
+      float4 wc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wc[k] = wn[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wn[k] = t0 + 4 + k < bw ? w4[(size_t)(t0 + 4 + k) * nq + qc] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (t0 + k >= bw) break;                              // uniform
+        const float wr[4] = {wc[k].x, wc[k].y, wc[k].z, wc[k].w};
+        const float4* row = reinterpret_cast<const float4*>(vs + (j0 + t0 + k) * VS + 8 * fg);
+#pragma unroll
+        for (int f2 = 0; f2 < 4; ++f2) {
+          const float4 x = row[f2];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[r][2 * f2].x = fmaf(wr[r], x.x, acc[r][2 * f2].x);         acc[r][2 * f2].y = fmaf(wr[r], x.y, acc[r][2 * f2].y);
+            acc[r][2 * f2 + 1].x = fmaf(wr[r], x.z, acc[r][2 * f2 + 1].x); acc[r][2 * f2 + 1].y = fmaf(wr[r], x.w, acc[r][2 * f2 + 1].y);
+          }
+        }
+      }
+    }
+    if (!qok) continue;
+    const bool wide = (nc & 1) == 0 && 4 * q + 3 < nc;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int64_t fr = f0 + 8 * fg + f;
+      if (fr >= n_frames) break;
+      cx<float>* o = hout + fr * nc + 4 * q;
+      if (wide) {
+        reinterpret_cast<float4*>(o)[0] = make_float4(acc[0][f].x, acc[0][f].y, acc[1][f].x, acc[1][f].y);
+        reinterpret_cast<float4*>(o)[1] = make_float4(acc[2][f].x, acc[2][f].y, acc[3][f].x, acc[3][f].y);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < nc) o[r] = acc[r][f];
+      }
+    }
+  }
+}
+
 // rows of the spline operator cut to their band, per quad of rows: w [bw][nq][4] (t-major), c0 [nq] = first column of the quad's
 // window, nq = ceil(nc / 4).  span = the largest number of columns the 64 quads of one workgroup of spline_band_kernel touch
 void mmse_band_spline(const std::vector<double>& sop, int nc, int np, std::vector<float>& w, std::vector<int32_t>& c0, int& bw, int& span) {
@@ -376,6 +473,14 @@ bool mmse_factored_usable(int np, int np_pad) { return np % 4 == 0 && np_pad % 1
 int mmse_factored_run(const void* mt, int np_pad, const float* sb_w, const int32_t* sb_c0, int bw, int span, const void* y, void* v,
                       void* hout, int np, int n_carrier, int64_t n_frames) {
   hipStream_t st = ctx().stream;
+  if (np_pad <= 256 && hout && !getenv("OFDM_MMSE_TWO_LAUNCHES")) {   // both factors in one launch
+    constexpr int ft = 32;                                     // (16 frames per workgroup, two workgroups per CU: 0.096 against 0.086 ms)
+    const size_t lds = sizeof(cx<float>) * (size_t)np_pad * (ft + 2);
+    (void)hipFuncSetAttribute((const void*)mmse_fused_kernel<ft>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mmse_fused_kernel<ft>, dim3((unsigned)((n_frames + ft - 1) / ft)), dim3(512), lds, st, (const cx<float>*)mt,
+                       (const cx<float>*)y, (const float4*)sb_w, sb_c0, bw, (cx<float>*)hout, np, np_pad, n_carrier, n_frames);
+    return check_launch("mmse_fused_kernel");
+  }
   int G = 4;                                                  // 32 rows x 32 frames per wavefront (G = 8 / 4 / 2 / 1 measured: 146 / 129 / 129 / 141 us per 8192 frames)
   if (const char* e = getenv("OFDM_MMSE_G")) G = atoi(e);
   const unsigned gy = (unsigned)(((np_pad + 31) / 32 + 3) / 4);
