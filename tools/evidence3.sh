@@ -12,6 +12,8 @@ step bench
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $out/bench_20steps.json 2> $out/bench.err
 t0=$SECONDS; timeout -k 10 600 python bench.py > $out/final_bench.json 2>> $out/bench.err || { echo "bench failed"; exit 1; }
 echo "python bench.py (defaults: M fp32 2000 steps + cpu_baseline + f64 leg + C2..C5): $((SECONDS - t0)) s wall" > $out/bench_wall.txt
+step smoke
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1 || echo "smoke failed"
 step stats
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu --no-f64 --no-secondary --steps 600 --warmup 40 > $out/stats_bench.json 2> $out/stats.err || { echo "stats pass failed"; exit 1; }
 cp $out/stats/*/*kernel_stats.csv $out/final_kernel_stats.csv
