@@ -307,6 +307,186 @@ static int demod_keep8192_run(const void* y, void* x, int64_t n_symb, int t_guar
   return launch(demod_keep8192_kernel<T, false>);
 }
 
+// ---- one pass for Nfft 8192 on the eight-wavefront transform above -----------------------------------------------------------
+// The symbols 2..S of a frame on demod_keep8192_kernel's transform (radix-2 step in registers, two NW = 8 transforms, the last
+// radix-8 pass pruned to the kept rows), but the rows never leave the registers they come out in: each thread holds four carriers
+// (2k', 2k'+1 for two k'), multiplies by its 1 ./ H (synthesised once per frame from the OMP taps, or read in MMSE mode), slices,
+// and the frame's decisions are packed and counted from LDS -- rx_symbols_kernel's frame loop around the 8192-point transform.
+// Sixteen wavefronts per CU (two 512-thread workgroups, 128 VGPRs) against the eight of rx_symbols_coop4_kernel (250 VGPRs, 79 KB).
+template <int BA, bool HEXT>
+__global__ __launch_bounds__(512, 4) void rx_symbols_r2_kernel(FastParams<float> P, const cx<float>* __restrict__ rx,
+                                                               const cx<float>* __restrict__ tw4096, const cx<float>* __restrict__ tw8192,
+                                                               int64_t n_frames, uint32_t* __restrict__ bits_out,
+                                                               const uint32_t* __restrict__ ref_bits, uint32_t* __restrict__ errors_out,
+                                                               cx<float>* __restrict__ h_out, int32_t* __restrict__ index_out,
+                                                               DemapTable<float> tab) {
+  using T = float;
+  constexpr int NW = 8, N = 8192, NOUT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cx<T>* lwv = (cx<T>*)smem;                                   // [NW][WAVE_LDS_ELEMS]
+  cx<T>* const ex = lwv;
+  cx<T>* twl = lwv + NW * WAVE_LDS_ELEMS;                      // [WAVE_TW_ELEMS]
+  uint8_t* codes = (uint8_t*)(twl + WAVE_TW_ELEMS);            // [n_symb * nd] (+ padding to 32)
+  __shared__ unsigned int sh_err;
+  __shared__ int sh_tidx[FAST_MAXT];
+  __shared__ c64 sh_tx[FAST_MAXT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gid = threadIdx.x;
+  DifTw<T, NW> dt;
+  wave_tw_fill<T, NW>(twl, tw4096);
+  dif_tw_init<T, NW>(dt, gid, tw4096);
+  cx<T> twb[7], w2[8];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) twb[t - 1] = tw4096[(t * (lane & 7) * 8) * NW];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) w2[t] = tw8192[gid + 512 * t];
+  // this thread's carriers: kc[2 t] = 2 k' (even half), kc[2 t + 1] = 2 k' + 1 (odd half), k' = NW (lane + 64 t) + wave
+  int kc[2 * NOUT], dd[2 * NOUT];
+  bool e = false, o = false;
+#pragma unroll
+  for (int t = 0; t < NOUT; ++t) {
+    const int k = 2 * (NW * (lane + 64 * t) + wave);
+    kc[2 * t] = k; kc[2 * t + 1] = k + 1;
+    dd[2 * t] = k < P.n_carrier ? (int)P.drole[k] : -1;
+    dd[2 * t + 1] = k + 1 < P.n_carrier ? (int)P.drole[k + 1] : -1;
+    e = e || dd[2 * t] >= 0;
+    o = o || dd[2 * t + 1] >= 0;
+  }
+  // a half whose rows hold no data carrier (comb pilots 1:4:end: the even half of every even wavefront) is skipped
+  const bool even_data = __any(e) != 0, odd_data = __any(o) != 0;
+  const int Lsym = N + P.t_guard;
+  const int taps = P.taps, bps = BA > 0 ? 2 * BA : P.bps, nd = P.nd;
+  const int n_codes = nd * P.n_symb;
+  if (gid < 32) codes[((n_codes + 31) & ~31) - 32 + gid] = 0;      // zero padding of the last 32-symbol group
+  __syncthreads();
+  for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    const cx<T>* frx = rx + f * (int64_t)Lsym * P.n_symb;
+    if (gid == 0) sh_err = 0;
+    if (!HEXT && gid < taps) {
+      const int idx = P.tap_idx[f * taps + gid];
+      sh_tidx[gid] = idx;
+      sh_tx[gid] = P.tap_x[f * taps + gid];
+      if (index_out) index_out[f * taps + gid] = idx + 1;
+    }
+    __syncthreads();
+    // ---- G = 1 ./ H on this thread's carriers: H = fft(h)(1..N_carrier) from the taps (OMP_estimate.m:36), or the MMSE estimate
+    cx<T> geq[2 * NOUT];
+#pragma unroll
+    for (int t = 0; t < 2 * NOUT; ++t) {
+      geq[t] = mk<T>(0, 0);
+      if (kc[t] < P.n_carrier) {
+        cx<T> H;
+        if constexpr (HEXT) {
+          H = P.h_in[f * P.n_carrier + kc[t]];
+        } else {
+          float hr = 0, hi = 0;                           // (fp32 sums: 32 terms of magnitude <= 1, the estimate itself is fp32)
+          for (int q = 0; q < taps; ++q) {
+            const int idx = sh_tidx[q];
+            const float xr = (float)sh_tx[q].x, xi = (float)sh_tx[q].y;      // zero for unused / overwritten slots
+            const int ee = ((idx < 0 ? 0 : idx) * kc[t]) & (N - 1);           // exact exponent (idx, k < 8192), v_sin / v_cos in turns
+            const float turns = (float)ee * (1.0f / (float)N);
+            const float ws = __builtin_amdgcn_sinf(turns), wc = __builtin_amdgcn_cosf(turns);
+            hr = fmaf(xr, wc, fmaf(xi, ws, hr));             // w = (wc, -ws)
+            hi = fmaf(xi, wc, fmaf(-xr, ws, hi));
+          }
+          H = mk<T>(hr, hi);
+        }
+        if (h_out) h_out[f * P.n_carrier + kc[t]] = H;
+        geq[t] = cdiv(mk<T>(1, 0), H);
+      }
+    }
+    // ---- symbol 1 from the stash
+#pragma unroll
+    for (int t = 0; t < 2 * NOUT; ++t)
+      if (dd[t] >= 0) codes[dd[t]] = (uint8_t)slice_symbol<T, BA>(tab, P.stash[f * P.n_carrier + kc[t]] * geq[t]);
+    // ---- symbols 2..S
+    for (int s = 1; s < P.n_symb; ++s) {
+      const cx<T>* src = frx + (int64_t)s * Lsym + P.t_guard;
+      cx<T> a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { a[t] = nt_load(src + gid + 512 * t); b[t] = nt_load(src + gid + 512 * t + 4096); }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const cx<T> d = a[t] - b[t];
+        a[t] = a[t] + b[t];
+        b[t] = d * w2[t];
+      }
+      // even bins
+      dif_stage<T, NW>(a, dt);
+      __syncthreads();                                           // every wavefront has left its private region
+      dif_scatter<T, NW>(a, gid, ex);
+      __syncthreads();
+      if (even_data) {                                           // wavefront-uniform
+        dif_gather<T>(a, wave, lane, ex);
+        wave_fft512<T, true>(a, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+        for (int t = 0; t < NOUT; ++t)
+          if (dd[2 * t] >= 0) codes[s * nd + dd[2 * t]] = (uint8_t)slice_symbol<T, BA>(tab, a[t] * geq[2 * t]);
+      }
+      // odd bins
+      dif_stage<T, NW>(b, dt);
+      __syncthreads();
+      dif_scatter<T, NW>(b, gid, ex);
+      __syncthreads();
+      if (odd_data) {
+        dif_gather<T>(b, wave, lane, ex);
+        wave_fft512<T, true>(b, lane, twb, twl, lwv + wave * WAVE_LDS_ELEMS);
+#pragma unroll
+        for (int t = 0; t < NOUT; ++t)
+          if (dd[2 * t + 1] >= 0) codes[s * nd + dd[2 * t + 1]] = (uint8_t)slice_symbol<T, BA>(tab, b[t] * geq[2 * t + 1]);
+      }
+    }
+    __syncthreads();
+    const unsigned int err = pack_frame<2 * BA>(codes, n_codes, bps, P.frame_words,
+                                                bits_out ? bits_out + f * P.frame_words : nullptr,
+                                                ref_bits ? ref_bits + f * P.frame_words : nullptr, gid, 512);
+    if (ref_bits && errors_out) {
+      if (err) atomicAdd(&sh_err, err);
+      __syncthreads();
+      if (gid == 0) errors_out[f] = sh_err;
+    }
+    __syncthreads();                     // codes / sh_err are reused by the next frame
+  }
+}
+
+static size_t r2_lds_bytes(const FastPlanView& pv) {
+  return sizeof(cx<float>) * ((size_t)8 * WAVE_LDS_ELEMS + WAVE_TW_ELEMS) + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+}
+static bool chain_r2_supported(const FastPlanView& pv) {
+  if (getenv("OFDM_SPLIT_NO_R2")) return false;
+  if (pv.f64 || pv.nfft != 8192 || pv.n_carrier > 2048 || pv.taps > FAST_MAXT || pv.n_symb < 1) return false;
+  return r2_lds_bytes(pv) <= 78u * 1024;                       // two workgroups per CU
+}
+static int chain_r2_symbols_run(const FastPlanView& pv, const FastParams<float>& P, const void* rx, int64_t n_frames, void* bits,
+                                const void* ref, void* errs, void* h_out, void* idx_out) {
+  const size_t lds = r2_lds_bytes(pv);
+  DemapTable<float> tab;
+  fill_demap_table<float>(*pv.dict, *pv.cinfo, tab);
+  const void *tw4 = nullptr, *tw8 = nullptr;
+  OFDM_TRY(get_twiddles(4096, false, &tw4));
+  OFDM_TRY(get_twiddles(8192, false, &tw8));
+  const bool mmse = pv.d_wt != nullptr;
+  auto launch = [&](auto kern) -> int {
+    int per_cu = resident_blocks_per_cu((const void*)kern, 512, lds);
+    if (const char* e = getenv("OFDM_R2_WG_PER_CU")) per_cu = std::max(1, atoi(e));
+    const unsigned grid = (unsigned)std::min<int64_t>(n_frames, (int64_t)ctx().num_cu * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx().stream, P, (const cx<float>*)rx, (const cx<float>*)tw4, (const cx<float>*)tw8,
+                       n_frames, (uint32_t*)bits, (const uint32_t*)ref, (uint32_t*)errs, (cx<float>*)h_out, (int32_t*)idx_out, tab);
+    return OFDM_OK;
+  };
+  const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
+#define R2_CASE(BAV)                                                   \
+  if (mmse) OFDM_TRY(launch(rx_symbols_r2_kernel<BAV, true>));         \
+  else OFDM_TRY(launch(rx_symbols_r2_kernel<BAV, false>))
+  switch (ba) {
+    case 2: R2_CASE(2); break;
+    case 3: R2_CASE(3); break;
+    case 4: R2_CASE(4); break;
+    default: R2_CASE(0); break;
+  }
+#undef R2_CASE
+  return check_launch("rx_symbols_r2_kernel");
+}
+
 bool chain_split_supported(int nfft, int n_carrier, int taps, int bps, int64_t nd_nsymb, bool f64) {
   if (getenv("OFDM_CHAIN_GENERIC")) return false;
   if (taps > FAST_MAXT || bps > 8) return false;
@@ -358,7 +538,8 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   OFDM_TRY(fast_params_prepare<T>(pv, tw, n_frames, P));
   const bool mmse = pv.d_wt != nullptr;
   if constexpr (std::is_same<T, float>::value) {
-    if (chain_coop_supported(pv)) {
+    const bool r2 = chain_r2_supported(pv);
+    if (r2 || chain_coop_supported(pv)) {
       // one pass over the samples (ofdm_chain_coop.hip): the first symbol of every frame -> stash + pilot LS values, the
       // estimator, then every other symbol transformed, equalised, sliced, packed and counted without an X round trip
       hipStream_t st = ctx().stream;
@@ -370,7 +551,8 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
       if (mmse) OFDM_TRY(mmse_stage_run<T>(pv, P, n_frames));
       else OFDM_TRY(omp_batch_run<T>(P, n_frames));
       if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[2], st));
-      OFDM_TRY(chain_coop_symbols_run(pv, P, rx, n_frames, bits, ref, errs, h_out, idx_out));
+      if (r2) OFDM_TRY(chain_r2_symbols_run(pv, P, rx, n_frames, bits, ref, errs, h_out, idx_out));
+      else OFDM_TRY(chain_coop_symbols_run(pv, P, rx, n_frames, bits, ref, errs, h_out, idx_out));
       if (pv.ev) OFDM_HIP(hipEventRecord(pv.ev[3], st));
       return OFDM_OK;
     }

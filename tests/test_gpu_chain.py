@@ -521,6 +521,43 @@ def test_metric_config_slicer_flips_are_boundary_points(ofdm, oracle, monkeypatc
     assert flips <= len(same)                                        # a handful in 1.4 M decisions, every one a near-tie
 
 
+@pytest.mark.parametrize("nc,comb,const,n_symb,taps_n,mode", [(2048, 4, "256QAM", 3, 32, "omp"), (1000, 2, "16QAM", 3, 4, "omp"),
+                                                               (1536, 8, "64QAM", 2, 5, "mmse"), (600, 4, "QPSK", 1, 3, "omp")])
+def test_chain_one_pass_8192_any_layout(ofdm, monkeypatch, nc, comb, const, n_symb, taps_n, mode):
+    """rx_symbols_r2_kernel (Nfft 8192, fp32, N_carrier <= 2048, ANY pilot layout: the frame loop of the symbol stage around the
+    eight-wavefront 8192-point transform; taken where rx_symbols_coop4_kernel does not apply, forced here by OFDM_SPLIT_NO_COOP)
+    against the split form (transform -> X in HBM -> equalise / demap) on the same frames."""
+    from ofdm_course_amd import frames as fr
+    for v in ("OFDM_CHAIN_GENERIC", "OFDM_SPLIT_NO_COOP", "OFDM_SPLIT_NO_R2"):
+        monkeypatch.delenv(v, raising=False)
+    rng = np.random.default_rng(nc + n_symb)
+    d = np.sort(rng.choice(min(nc // 4 - 1, 400), taps_n, replace=False))
+    d[0] = 0
+    taps = np.stack([d.astype(float), np.linspace(1.0, 0.3, taps_n) * np.exp(1j * rng.uniform(0, 6.28, taps_n))], axis=1)
+    cfg = fr.FrameConfig("one-pass-r2", 8192, nc, comb, const, N_symb=n_symb, taps=taps, dominant_taps=taps_n, SNR_dB=30.0)
+    nfr = 9
+    data = fr.make_frames(cfg, ofdm, nfr, seed=13, precision="fp32", noise_first=True)
+    plan = fr.make_plan(cfg, ofdm, precision="fp32")
+    nb = data["bits"].shape[1]
+    if mode == "mmse":
+        h, _ = ofdm.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+        hh = np.zeros(cfg.N_carrier, dtype=np.complex128)
+        hh[: len(h)] = h
+        plan.set_mmse(hh, cfg.SNR_dB)
+    monkeypatch.setenv("OFDM_SPLIT_NO_COOP", "1")
+    out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=mode == "omp")
+    monkeypatch.setenv("OFDM_SPLIT_NO_R2", "1")
+    old = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=mode == "omp")
+    got_bits = fr.unpack_bits(np.asarray(out["bits"]), nb)
+    old_bits = fr.unpack_bits(np.asarray(old["bits"]), nb)
+    assert rel_l2(np.asarray(out["H"]), np.asarray(old["H"])) < 2e-5
+    assert np.count_nonzero(got_bits != old_bits) <= 2 * nfr
+    assert np.array_equal(np.count_nonzero(got_bits != data["bits"], axis=1), np.asarray(out["errors"]).astype(np.int64))
+    if mode == "omp":
+        assert np.array_equal(np.asarray(out["index"]), np.asarray(old["index"]))
+    plan.close()
+
+
 @pytest.mark.parametrize("nc,const,n_symb,taps_n,mode", [(2048, "256QAM", 3, 32, "omp"), (1024, "64QAM", 4, 6, "omp"),
                                                           (512, "16QAM", 1, 3, "omp"), (256, "QPSK", 2, 2, "omp"),
                                                           (1024, "16QAM", 5, 3, "mmse")])
@@ -529,7 +566,7 @@ def test_chain_one_pass_8192(ofdm, oracle, monkeypatch, nc, const, n_symb, taps_
     2048-point transform, H by one more transform of the taps, symbol 1 from the stash) against the oracle and against the
     split form (OFDM_SPLIT_NO_COOP) on the same frames: frames of 1 .. 5 symbols, 2 .. 32 taps, a ragged batch, MMSE mode."""
     from ofdm_course_amd import frames as fr
-    for v in ("OFDM_CHAIN_GENERIC", "OFDM_SPLIT_NO_COOP"):
+    for v in ("OFDM_CHAIN_GENERIC", "OFDM_SPLIT_NO_COOP", "OFDM_SPLIT_NO_R2"):
         monkeypatch.delenv(v, raising=False)
     rng = np.random.default_rng(nc + n_symb)
     d = np.sort(rng.choice(min(nc // 4 - 1, 400), taps_n, replace=False))
@@ -548,8 +585,10 @@ def test_chain_one_pass_8192(ofdm, oracle, monkeypatch, nc, const, n_symb, taps_
         plan.set_mmse(hh, cfg.SNR_dB)
     out = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=mode == "omp")
     monkeypatch.setenv("OFDM_SPLIT_NO_COOP", "1")
+    monkeypatch.setenv("OFDM_SPLIT_NO_R2", "1")
     old = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_h=True, want_index=mode == "omp")
     monkeypatch.delenv("OFDM_SPLIT_NO_COOP")
+    monkeypatch.delenv("OFDM_SPLIT_NO_R2")
     got_bits = fr.unpack_bits(np.asarray(out["bits"]), nb)
     old_bits = fr.unpack_bits(np.asarray(old["bits"]), nb)
     assert rel_l2(np.asarray(out["H"]), np.asarray(old["H"])) < 2e-5

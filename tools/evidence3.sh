@@ -30,7 +30,8 @@ for c in c3 c4 c5; do
   C5_WARM_S=0.02 bash tools/pmc_cmd.sh $out/${c}_pmc python tools/${c}_run.py $pargs > $out/${c}_pmc_summary.txt 2>&1
 done
 step c5_split
-OFDM_SPLIT_NO_COOP=1 timeout -k 10 300 python tools/c5_run.py 3072 20 > $out/c5_split_form.txt 2>&1
+OFDM_SPLIT_NO_COOP=1 OFDM_SPLIT_NO_R2=1 timeout -k 10 300 python tools/c5_run.py 3072 20 > $out/c5_split_form.txt 2>&1
+OFDM_SPLIT_NO_COOP=1 timeout -k 10 300 python tools/c5_run.py 3072 20 > $out/c5_r2_form.txt 2>&1
 step sweep
 timeout -k 10 300 python -m ofdm_course_amd.drivers.sweep_ber --config C5 --batches 2 --frames-per-tile 64 --json $out/sweep_c5.json > /dev/null 2>&1
 step pmc
