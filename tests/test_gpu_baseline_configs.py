@@ -119,6 +119,37 @@ def test_c4_mmse_chain(ofdm, oracle):
     assert tot_g == tot_o and 0 < tot_g < 0.2 * data["bits"].size
 
 
+def test_c4_full_tile_properties(ofdm, monkeypatch):
+    """configs[3] at the benchmark tile (8192 frames of 14 symbols, fp32 plan in MMSE mode, frames generated on the device in the
+    reference's channel order): size-independent properties -- the one-launch MMSE stage gives the bits of the two-launch form
+    (mmse_fused_kernel / mmse_apply_mfma_kernel + spline_band_kernel: same products, same order), the error counts equal the
+    popcount of bits XOR reference, the first 24 frames alone give the same bits (batching independence), BER in the range of
+    the operating point."""
+    import torch
+    from ofdm_course_amd import frames as fr
+    cfg = fr.FrameConfig("C4", 4096, 1024, 4, "64QAM")
+    plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
+    F = 8192
+    data = fr.make_frames_device(cfg, ofdm, plan, F, seed=4, device=torch.device("cuda:0"), noise_first=True)
+    h, _ = ofdm.get_MP_channel_resp(cfg.taps, cfg.Nfft)
+    hh = np.zeros(cfg.N_carrier, dtype=np.complex64)
+    hh[: len(h)] = h
+    plan.set_mmse(hh, cfg.SNR_dB)
+    a = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"])
+    monkeypatch.setenv("OFDM_MMSE_TWO_LAUNCHES", "1")
+    b = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"])
+    monkeypatch.delenv("OFDM_MMSE_TWO_LAUNCHES")
+    assert torch.equal(a["bits"], b["bits"]) and torch.equal(a["errors"], b["errors"])
+    x = (a["bits"] ^ data["packed"]).cpu().numpy()                                     # [F, frame_bytes] uint8
+    pop = np.unpackbits(x, axis=1).sum(axis=1)
+    assert np.array_equal(pop.astype(np.int64), a["errors"].cpu().numpy().astype(np.int64))
+    small = ofdm.rx_chain_task5(plan, data["rx"][:, :24], ref_bits_packed=data["packed"][:24])
+    assert torch.equal(small["bits"], a["bits"][:24])
+    ber = float(a["errors"].sum().item()) / (F * plan.frame_bits)
+    assert 1e-3 < ber < 3e-2
+    plan.close()
+
+
 def test_c5_snr_sweep_tiles(ofdm, oracle):
     """configs[4]: Nfft=8192, 256-QAM, sparse 32-tap channel, OMP, SNR sweep dealt as (snr, batch) tiles.
     Tiles of two ranks reproduce the single-rank totals (the sum the RCCL all-reduce forms), and one tile is
