@@ -150,6 +150,76 @@ def test_c4_full_tile_properties(ofdm, monkeypatch):
     plan.close()
 
 
+def test_c3_full_tile_properties(ofdm):
+    """configs[2] at the benchmark tile (4096 frames of 50 symbols, every frame with its own STO / CFO draw from ONE
+    ofdm_tx_frames_ex call): size-independent properties of the batched Task-4 receiver -- every frame finds its IFO line, the
+    recovered TgPosition is the drawn Time_Delay up to the channel's first taps, FreqOffset + IFO give back the drawn
+    Freq_Shift, error counts equal the popcount of bits XOR payload, the first 8 frames alone give the same outputs."""
+    import torch
+    from ofdm_course_amd.drivers import common as dc
+    Nfft, Tg, N_carrier, N_symb, const = 2048, 256, 800, 50, "64QAM"
+    allc, pil, dat = dc.layout_percent(Nfft, N_carrier, 15, tail=2)
+    d, bps = ofdm.constellation_func(const)
+    pv = dc.alternating_pilots(4 / 3 * float(np.max(np.abs(d))), len(pil), N_symb)
+    h, _ = ofdm.get_MP_channel_resp(np.array([[0, 1.0], [4, 0.6], [10, 0.3]]), Nfft)
+    plan = ofdm.RxPlan(Nfft, Tg, N_symb, N_carrier, pil, dat, pv[:, 0], int(np.ceil(N_carrier / 6)), 3, const, precision="fp32", device=0)
+    F = 4096
+    gen = plan.tx_frames(F, h=h, SNR=30.0, seed=9, device=torch.device("cuda:0"), Time_Delay="random", Freq_Shift="random",
+                         noise_first=True, want_draws=True)
+    out = ofdm.rx_chain_task4(plan, gen["rx"], 1, 1, 1, ref_bits_packed=gen["packed"])
+    st = out["status"].cpu().numpy()
+    assert (st >= 0).all()
+    tg = out["TgPosition"].cpu().numpy()
+    sto = gen["Time_Delay"].cpu().numpy()
+    dd = (tg + sto) % (Nfft + Tg)                                    # the coarse estimate lands on the guard-interval plateau of the
+    dd = np.minimum(dd, Nfft + Tg - dd)                              # delayed stream (fine_sync removes what is left)
+    assert dd.max() <= Tg, dd.max()
+    cfo = gen["Freq_Shift"].cpu().numpy()
+    est = out["FreqOffset"].cpu().numpy() + out["IFO"].cpu().numpy()
+    diff = est - cfo                                                 # the fractional part always; the integer part wherever remove_IFO's
+    assert np.abs(diff - np.round(diff)).max() < 0.05                # line search lands on the drawn line.  It lands 1..4 lines low on
+    ok_int = np.round(diff) == 0                                     # ~29 % of these draws (never high) and such a frame decodes to BER 0.5:
+    assert ok_int.mean() > 0.6, ok_int.mean()                        # the restated remove_IFO.m does the same frame by frame
+    assert (np.round(diff)[~ok_int] < 0).all()                       # (test_gpu_task4_batch.py compares them with the oracle)
+    x = (out["bits"] ^ gen["packed"]).cpu().numpy()
+    assert np.array_equal(np.unpackbits(x, axis=1).sum(axis=1).astype(np.int64), out["errors"].cpu().numpy().astype(np.int64))
+    ber = out["errors"].cpu().numpy().astype(np.float64) / plan.frame_bits
+    assert np.median(ber[ok_int]) < 0.2 and (ber[~ok_int] > 0.3).all()
+    small = ofdm.rx_chain_task4(plan, gen["rx"][:, :8], 1, 1, 1, ref_bits_packed=gen["packed"][:8])
+    assert torch.equal(small["bits"], out["bits"][:8]) and torch.equal(small["TgPosition"], out["TgPosition"][:8])
+    plan.close()
+
+
+def test_c5_full_tile_properties(ofdm, monkeypatch):
+    """configs[4] at the benchmark tile (3072 frames, Nfft 8192, 256-QAM, OMP with 32 taps): the three forms of the symbol stage
+    (rx_symbols_coop4_kernel, rx_symbols_r2_kernel, split form) pick the same atoms and agree on the error count of every frame
+    up to the handful of decisions their differently rounded H moves; counts == popcount; batching independence."""
+    import torch
+    from ofdm_course_amd import frames as fr
+    for v in ("OFDM_CHAIN_GENERIC", "OFDM_SPLIT_NO_COOP", "OFDM_SPLIT_NO_R2"):
+        monkeypatch.delenv(v, raising=False)
+    cfg = fr.config_C5()
+    plan = fr.make_plan(cfg, ofdm, precision="fp32", device=0)
+    F = 3072
+    data = fr.make_frames_device(cfg, ofdm, plan, F, seed=5, device=torch.device("cuda:0"), noise_first=True)
+    a = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_index=True)
+    monkeypatch.setenv("OFDM_SPLIT_NO_COOP", "1")
+    b = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_index=True)
+    monkeypatch.setenv("OFDM_SPLIT_NO_R2", "1")
+    c = ofdm.rx_chain_task5(plan, data["rx"], ref_bits_packed=data["packed"], want_index=True)
+    monkeypatch.delenv("OFDM_SPLIT_NO_COOP")
+    monkeypatch.delenv("OFDM_SPLIT_NO_R2")
+    assert torch.equal(a["index"], b["index"]) and torch.equal(a["index"], c["index"])
+    ea, eb, ec = (t["errors"].cpu().numpy().astype(np.int64) for t in (a, b, c))
+    assert np.abs(ea - ec).max() <= 8 and np.abs(eb - ec).max() <= 8
+    assert abs(int(ea.sum()) - int(ec.sum())) <= 1e-5 * ec.sum() and abs(int(eb.sum()) - int(ec.sum())) <= 1e-5 * ec.sum()
+    x = (a["bits"] ^ data["packed"]).cpu().numpy()
+    assert np.array_equal(np.unpackbits(x, axis=1).sum(axis=1).astype(np.int64), ea)
+    small = ofdm.rx_chain_task5(plan, data["rx"][:, :16], ref_bits_packed=data["packed"][:16])
+    assert torch.equal(small["bits"], a["bits"][:16])
+    plan.close()
+
+
 def test_c5_snr_sweep_tiles(ofdm, oracle):
     """configs[4]: Nfft=8192, 256-QAM, sparse 32-tap channel, OMP, SNR sweep dealt as (snr, batch) tiles.
     Tiles of two ranks reproduce the single-rank totals (the sum the RCCL all-reduce forms), and one tile is
