@@ -41,6 +41,7 @@ step clock
 if [ -f ofdm-course_amd/libofdm_mi355x_diag.so ]; then bash tools/clock_probe.sh $out/clock > $out/clock_probe.txt 2>&1; fi
 step ubench
 tools/ubench/hbm_read > $out/hbm_read.txt 2>&1
+[ -x tools/ubench/hbm_copy ] && tools/ubench/hbm_copy > $out/hbm_copy.txt 2>&1
 # raw per-dispatch tables stay on the box: only the summaries travel (gpurun merges at most 64 MiB)
 rm -rf $out/stats $out/stats64 $out/c5_stats $out/c3_stats $out/c4_stats $out/pmc/*/ $out/c5_pmc/*/ $out/c3_pmc/*/ $out/c4_pmc/*/ $out/clock
 du -sh $out >> $out/progress.txt
