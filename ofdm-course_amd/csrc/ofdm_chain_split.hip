@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void pilot_ls_kernel(FastParams<T> P, const cx
 }
 
 // one workgroup per frame (grid-stride): G = 1 ./ H in LDS, then every symbol's data carriers
-template <typename T, int BA, bool HEXT>
+// VEC (fp32, N_carrier and the row stride even): a thread takes PAIRS of neighbouring carriers with one 16-byte load per (pair,
+// symbol), four symbols x two pairs requested together, and decides every carrier it loads -- a carrier without data (pilot, or
+// past N_carrier) stores its decision to a dump byte behind the codes: no exec-mask branch per sample, half the load
+// instructions, twice the bytes in flight of the 8-byte form.
+template <typename T, int BA, bool HEXT, bool VEC = false>
 __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft, const cx<T>* __restrict__ xk,
                                                        int x_stride /* rows per symbol column of xk */, int64_t n_frames, uint32_t* __restrict__ bits_out,
                                                        const uint32_t* __restrict__ ref_bits,
@@ -127,34 +131,78 @@ __global__ __launch_bounds__(256) void eq_demap_kernel(FastParams<T> P, int nfft
     }
     __syncthreads();
     const cx<T>* xf = xk + f * P.n_symb * (int64_t)x_stride;
-    // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by the bytes it
-    // keeps in flight (a register double buffer of the next step was measured: 170 VGPRs, half the wavefronts, slower)
-    for (int k0 = gid; k0 < nc; k0 += 8 * 256) {
-      int dv[8];
+    if constexpr (VEC) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const int dump = (n_codes + 31) & ~31;                           // one byte behind the zero padding
+      for (int k0 = 2 * gid; k0 < nc; k0 += 2 * 512) {
+        int ci[2][2], cinc[2][2];
+        cx<T> g[2][2];
+        const cx<T>* xp[2];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + 256 * u;
-        dv[u] = k < nc ? (int)P.drole[k] : -1;
-      }
-      for (int s0 = 0; s0 < P.n_symb; s0 += 2) {
-        cx<T> xv[2][8];
+        for (int u = 0; u < 2; ++u) {
+          const int k = k0 + 512 * u;
+          const bool act = k < nc;                                     // k even, nc even: k + 1 < nc as well
+          const int kc = act ? k : 0;
+          xp[u] = xf + kc;
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+          for (int h = 0; h < 2; ++h) {
+            const int d = act ? (int)P.drole[kc + h] : -1;
+            ci[u][h] = d >= 0 ? d : dump;
+            cinc[u][h] = d >= 0 ? nd : 0;
+            g[u][h] = geq[kc + h];
+          }
+        }
+        for (int s0 = 0; s0 < P.n_symb; s0 += 4) {
+          v4f xv[4][2];
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? nt_load(xf + (int64_t)(s0 + v) * x_stride + k0 + 256 * u) : mk<T>(0, 0);
+          for (int v = 0; v < 4; ++v)
+            if (s0 + v < P.n_symb) {                                   // workgroup-uniform
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (dv[u] >= 0 && s0 + v < P.n_symb) {
-              const cx<T> xs = xv[v][u];
-              const cx<T> ye = xs * geq[k0 + 256 * u];
-              int code;
-              if constexpr (BA >= 2 && sizeof(T) == 8) code = demap_square_lut<T, BA>(tab, sh_lut, ye);   // parity mode: exact, 9 ops / axis
-              else code = slice_symbol<T, BA>(tab, ye);                                                  // fp32: arithmetic rank
-              codes[(s0 + v) * nd + dv[u]] = (uint8_t)code;
+              for (int u = 0; u < 2; ++u)
+                xv[v][u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(xp[u] + (int64_t)(s0 + v) * x_stride));
             }
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (s0 + v < P.n_symb) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const cx<T> y0 = mk<T>(xv[v][u].x, xv[v][u].y) * g[u][0], y1 = mk<T>(xv[v][u].z, xv[v][u].w) * g[u][1];
+                codes[ci[u][0] + (s0 + v) * cinc[u][0]] = (uint8_t)slice_symbol<T, BA>(tab, y0);
+                codes[ci[u][1] + (s0 + v) * cinc[u][1]] = (uint8_t)slice_symbol<T, BA>(tab, y1);
+              }
+            }
+        }
+      }
+    } else {
+    // 2 symbols x 8 carriers per thread requested together: this stage streams X(1..N_carrier, :) and is bound by the bytes it
+      // keeps in flight (a register double buffer of the next step was measured: 170 VGPRs, half the wavefronts, slower)
+      for (int k0 = gid; k0 < nc; k0 += 8 * 256) {
+        int dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 256 * u;
+          dv[u] = k < nc ? (int)P.drole[k] : -1;
+        }
+        for (int s0 = 0; s0 < P.n_symb; s0 += 2) {
+          cx<T> xv[2][8];
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              xv[v][u] = (dv[u] >= 0 && s0 + v < P.n_symb) ? nt_load(xf + (int64_t)(s0 + v) * x_stride + k0 + 256 * u) : mk<T>(0, 0);
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (dv[u] >= 0 && s0 + v < P.n_symb) {
+                const cx<T> xs = xv[v][u];
+                const cx<T> ye = xs * geq[k0 + 256 * u];
+                int code;
+                if constexpr (BA >= 2 && sizeof(T) == 8) code = demap_square_lut<T, BA>(tab, sh_lut, ye);   // parity mode: exact, 9 ops / axis
+                else code = slice_symbol<T, BA>(tab, ye);                                                  // fp32: arithmetic rank
+                codes[(s0 + v) * nd + dv[u]] = (uint8_t)code;
+              }
+        }
       }
     }
     __syncthreads();
@@ -503,7 +551,9 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
   hipStream_t st = ctx().stream;
   DemapTable<T> tab;
   fill_demap_table<T>(*pv.dict, *pv.cinfo, tab);
-  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31));
+  const size_t dyn = sizeof(cx<T>) * (size_t)pv.n_carrier + (((size_t)pv.nd * pv.n_symb + 31) & ~size_t(31)) + 16;
+  const bool vec = std::is_same<T, float>::value && (pv.n_carrier & 1) == 0 && (x_stride & 1) == 0 && pv.n_carrier <= 2048 &&
+                   !getenv("OFDM_EQD_SCALAR");
   OFDM_ARG(dyn <= 150 * 1024, "rx_chain: equalise / demap stage needs %zu bytes of LDS", dyn);
   auto launch = [&](auto kern) -> int {
     int per_cu = resident_blocks_per_cu((const void*)kern, 256, dyn);
@@ -516,6 +566,12 @@ int eq_demap_run(const FastPlanView& pv, const FastParams<T>& P, const cx<T>* xk
   };
   const int ba = pv.cinfo->kind == 1 ? pv.cinfo->bits_per_axis : 0;
 #define SPLIT_CASE(BAV)                                                                                    \
+  if constexpr (std::is_same<T, float>::value) {                                                           \
+    if (vec) {                                                                                             \
+      if (hext) OFDM_TRY(launch(eq_demap_kernel<T, BAV, true, true>)); else OFDM_TRY(launch(eq_demap_kernel<T, BAV, false, true>)); \
+      break;                                                                                               \
+    }                                                                                                      \
+  }                                                                                                        \
   if (hext) OFDM_TRY(launch(eq_demap_kernel<T, BAV, true>)); else OFDM_TRY(launch(eq_demap_kernel<T, BAV, false>))
   switch (ba) {
     case 2: SPLIT_CASE(2); break;
