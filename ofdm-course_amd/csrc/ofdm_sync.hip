@@ -445,6 +445,9 @@ __device__ double fine_phase_body(const PilotView<T>& pv, int time_desync, doubl
   int64_t (&wn)[FS_THREADS / 64] = sc.wn;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned M = (unsigned)pv.M;
+  // i mod np by a multiply (exact while i * np < 2^32: frames of up to 65535 pilot samples), else the division
+  const unsigned npu = (unsigned)pv.np, magic = (M < 65536u && npu < 65536u) ? 0xFFFFFFFFu / npu + 1u : 0u;
+  auto mod_np = [&](unsigned i) { return magic ? i - __umulhi(i, magic) * npu : i % npu; };
   double sum = 0.0;
   int64_t cnt = 0;
   for (unsigned base = 0; base < M; base += FS_THREADS * FS_U) {
@@ -462,8 +465,8 @@ __device__ double fine_phase_body(const PilotView<T>& pv, int time_desync, doubl
         if (time_desync) {
           // rx' = rx * exp(+2 pi j tau k)  =>  q' = q * exp(-2 pi j tau k)   (fine_sync.m:25-27, nn_exp')
           double sn, cs;
-          if (rot_tab) { const double2 r = rot_tab[i % (unsigned)pv.np]; cs = r.x; sn = r.y; }
-          else fine_rot<T>(tau, pv.pc0[i % (unsigned)pv.np], cs, sn);
+          if (rot_tab) { const double2 r = rot_tab[mod_np(i)]; cs = r.x; sn = r.y; }
+          else fine_rot<T>(tau, pv.pc0[mod_np(i)], cs, sn);
           const double r2 = qr[u] * cs + qi[u] * sn, i2 = qi[u] * cs - qr[u] * sn;
           qr[u] = r2; qi[u] = i2;
         }
