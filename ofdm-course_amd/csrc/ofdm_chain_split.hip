@@ -594,8 +594,9 @@ static int split_run(const FastPlanView& pv, const void* tw, const void* rx, int
   OFDM_TRY(fast_params_prepare<T>(pv, tw, n_frames, P));
   const bool mmse = pv.d_wt != nullptr;
   if constexpr (std::is_same<T, float>::value) {
-    const bool r2 = chain_r2_supported(pv);
-    if (r2 || chain_coop_supported(pv)) {
+    const bool coop = chain_coop_supported(pv);                        // (the faster one where its layout conditions hold)
+    const bool r2 = !coop && chain_r2_supported(pv);
+    if (r2 || coop) {
       // one pass over the samples (ofdm_chain_coop.hip): the first symbol of every frame -> stash + pilot LS values, the
       // estimator, then every other symbol transformed, equalised, sliced, packed and counted without an X round trip
       hipStream_t st = ctx().stream;
