@@ -68,6 +68,27 @@ def _per_function(ofdm, rx, d, cfg_kw, flags):
     return out
 
 
+@pytest.mark.parametrize("nfft,nc", [(1024, 401), (1024, 398), (512, 127), (2048, 1021), (2048, 800)])
+def test_batch_banded_spline_equals_dense_product(ofdm, monkeypatch, nfft, nc):
+    """estimate_channel.m:8 of the fp32 batch: spline_band_kernel (a quad of rows x 8 frames per thread, rows cut to the columns that
+    reach 1e-10 of their largest weight) against the dense tile product (OFDM_T4_DENSE_SPLINE) on the same frames -- odd carrier
+    counts, counts that are not a multiple of four, fewer than 64 quads, a ragged frame count."""
+    from ofdm_course_amd import frames as fr
+    cfg_kw = dict(Nfft=nfft, N_carrier=nc, N_symb=4, const="16QAM")
+    nfr = 11
+    d = _frames(ofdm, cfg_kw, nfr, "fp32", seed=5)
+    plan = ofdm.RxPlan(nfft, d["Tg"], 4, nc, d["pil"], d["dat"], d["col"], int(np.ceil(nc / 6)), 3, "16QAM", precision="fp32")
+    packed = fr.pack_bits(d["bits"])
+    monkeypatch.delenv("OFDM_T4_DENSE_SPLINE", raising=False)
+    a = ofdm.rx_chain_task4(plan, d["rx"], 0, 0, 1, ref_bits_packed=packed, want_h=True)
+    monkeypatch.setenv("OFDM_T4_DENSE_SPLINE", "1")
+    b = ofdm.rx_chain_task4(plan, d["rx"], 0, 0, 1, ref_bits_packed=packed, want_h=True)
+    ha, hb = np.asarray(a["H"]), np.asarray(b["H"])
+    assert np.all(np.isfinite(ha)) and rel_l2(ha, hb) < 2e-6
+    assert np.count_nonzero(np.asarray(a["bits"]) != np.asarray(b["bits"])) <= 2
+    plan.close()
+
+
 @pytest.mark.parametrize("staged", [False, True])
 @pytest.mark.parametrize("precision", ["fp64", "fp32"])
 @pytest.mark.parametrize("flags", [(1, 1, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)])
